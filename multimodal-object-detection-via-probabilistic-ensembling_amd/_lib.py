@@ -1,0 +1,65 @@
+"""ctypes binding of libproben_hip.so (include/proben_hip.h).  Fails loudly."""
+import ctypes
+import os
+
+import torch
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libproben_hip.so")
+_lib = None
+
+c_void_p, c_int, c_double, c_float = ctypes.c_void_p, ctypes.c_int32, ctypes.c_double, ctypes.c_float
+
+# name -> argtypes (restype is always int unless listed in _RESTYPE)
+SIGNATURES = {
+    "pe_version": [],
+    "pe_proben_fuse_batch": [c_void_p] * 6 + [c_int] * 5 + [c_double] * 3 + [c_void_p] * 5 + [c_void_p],
+}
+_RESTYPE = {"pe_last_error": ctypes.c_char_p}
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded library; raises HipLibraryError when it was not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipLibraryError(
+                f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  proben_amd has no CPU fallback.")
+        L = ctypes.CDLL(LIB_PATH)
+        L.pe_last_error.restype = ctypes.c_char_p
+        L.pe_last_error.argtypes = []
+        for name, args in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError here = header/library mismatch
+            fn.argtypes = args
+            fn.restype = ctypes.c_int
+        _lib = L
+    return _lib
+
+
+def check(status, what):
+    if status != 0:
+        raise HipLibraryError(f"{what} failed ({status}): {lib().pe_last_error().decode()}")
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise HipLibraryError("proben_amd kernels need device tensors (MODEL.DEVICE=cuda); got a CPU tensor. "
+                                  "There is no CPU fallback in the product path.")
+
+
+def ptr(t):
+    """Device pointer of a contiguous tensor (None -> NULL)."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "tensor must be contiguous"
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

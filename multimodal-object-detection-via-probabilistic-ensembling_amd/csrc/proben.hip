@@ -1,0 +1,267 @@
+// ProbEn late fusion for gfx950: ONE WAVEFRONT PER IMAGE, whole per-image state in LDS.
+//
+// Replaces the reference's per-image NumPy loop (demo/FLIR/demo_probEn.py:92-187 nms_bayesian,
+// :32-42 bayesian_fusion_multiclass, :24-30 bayesian_fusion, :73-77 weighted_box_fusion,
+// :20-22 avg_bbox_fusion).  float64 throughout (the reference's NumPy dtype); compiled with
+// -ffp-contract=off so IoU decisions round exactly like the reference's separate mul/add/div.
+//
+// Kernel shape: the greedy clustering is inherently sequential in the pivot (<= N pivots per
+// image), so parallelism comes from (a) 64 lanes scoring the pivot against 64 candidates per
+// step with a ballot-compacted member list, (b) per-row logs / geometry precomputed in parallel,
+// (c) thousands of images in flight (one wave each, <= 32 waves per CU).  Per image the HBM
+// traffic is N*(4+1+K+1)*8 + N*4 bytes in and M*(32+4+4+4) bytes out; everything else stays in LDS.
+#include "common.h"
+
+namespace {
+
+struct ProbenArgs {
+    const double* boxes;
+    const double* scores;
+    const double* probs;
+    const double* vars;
+    const int32_t* classes;
+    const int32_t* offsets;
+    int32_t B, K, max_rows, score_mode, box_mode;
+    double thr, fw, fh;
+    double* out_boxes;
+    float* out_scores;
+    float* out_classes;
+    int32_t* out_keep;
+    int32_t* out_counts;
+};
+
+// Sort rule shared with oracle/proben.py: NaN first, score descending, ties by ORIGINAL index
+// descending (== reversed stable ascending argsort, the reference's `argsort()[::-1]`).
+__device__ __forceinline__ bool precedes(double sa, int ia, double sb, int ib) {
+    const bool na = sa != sa, nb = sb != sb;
+    if (na != nb) return na;
+    if (!na && sa != sb) return sa > sb;
+    return ia > ib;
+}
+
+__global__ __launch_bounds__(64) void proben_fuse_kernel(ProbenArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int img = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int beg = a.offsets[img];
+    const int n = a.offsets[img + 1] - beg;
+    if (n > a.max_rows || n < 0) {
+        if (lane == 0) a.out_counts[img] = -1;
+        return;
+    }
+    const int R = a.max_rows;
+    const int K = a.K;
+    // columns of log-probabilities kept per row (0 when the score mode does not need them)
+    const int L = (a.score_mode == PE_SCORE_PROBEN) ? K + 1 : (a.score_mode == PE_SCORE_PROBEN_BINARY ? 2 : 0);
+    // ---- LDS carve (all arrays indexed by SORTED position unless noted) ----
+    double* gx1 = reinterpret_cast<double*>(smem);
+    double* gy1 = gx1 + R;
+    double* gx2 = gy1 + R;
+    double* gy2 = gx2 + R;
+    double* gar = gy2 + R;
+    double* gsc = gar + R;   // score
+    double* glog = gsc + R;  // [L][R]
+    int* ord = reinterpret_cast<int*>(glog + (size_t)L * R);  // sorted position -> original row
+    unsigned short* members = reinterpret_cast<unsigned short*>(ord + R);
+    unsigned char* alive = reinterpret_cast<unsigned char*>(members + R);
+
+    // ---- 1. rank sort by score (scores staged through gar, indexed by ORIGINAL row) ----
+    for (int r = lane; r < n; r += 64) gar[r] = a.scores[beg + r];
+    __syncthreads();
+    for (int r = lane; r < n; r += 64) {
+        const double s = gar[r];
+        int rank = 0;
+        for (int q = 0; q < n; ++q) rank += precedes(gar[q], q, s, r) ? 1 : 0;
+        ord[rank] = r;
+        gsc[rank] = s;
+    }
+    __syncthreads();
+    // ---- 2. per-row geometry (class-band shifted, legacy "+1" area) and log-probabilities ----
+    for (int p = lane; p < n; p += 64) {
+        const int r = ord[p];
+        const double c = (double)a.classes[beg + r];
+        const double* b = a.boxes + (size_t)(beg + r) * 4;
+        const double x1 = b[0] + c * a.fw, y1 = b[1] + c * a.fh;
+        const double x2 = b[2] + c * a.fw, y2 = b[3] + c * a.fh;
+        gx1[p] = x1; gy1[p] = y1; gx2[p] = x2; gy2[p] = y2;
+        gar[p] = (x2 - x1 + 1.0) * (y2 - y1 + 1.0);
+        alive[p] = 1;
+        if (a.score_mode == PE_SCORE_PROBEN) {
+            const double* pr = a.probs + (size_t)(beg + r) * K;
+            double sum = 0.0;
+            for (int j = 0; j < K; ++j) {
+                const double pj = pr[j];
+                sum += pj;
+                glog[(size_t)j * R + p] = log(pj);
+            }
+            glog[(size_t)K * R + p] = log(1.0 - sum);
+        } else if (a.score_mode == PE_SCORE_PROBEN_BINARY) {
+            const double s = gsc[p];
+            glog[p] = log(s);
+            glog[(size_t)R + p] = log(1.0 - s);
+        }
+    }
+    __syncthreads();
+
+    // ---- 3. greedy pivots ----
+    int m_out = 0;
+    for (int pos = 0; pos < n; ++pos) {
+        if (!alive[pos]) continue;  // wave-uniform (LDS broadcast)
+        const double px1 = gx1[pos], py1 = gy1[pos], px2 = gx2[pos], py2 = gy2[pos], par = gar[pos];
+        int cnt = 0;
+        for (int base = pos + 1; base < n; base += 64) {
+            const int q = base + lane;
+            bool match = false;
+            if (q < n && alive[q]) {
+                const double w = fmax(0.0, fmin(px2, gx2[q]) - fmax(px1, gx1[q]) + 1.0);
+                const double h = fmax(0.0, fmin(py2, gy2[q]) - fmax(py1, gy1[q]) + 1.0);
+                const double inter = w * h;
+                const double ovr = inter / (par + gar[q] - inter);
+                match = ovr > a.thr;
+                if (!(ovr <= a.thr)) alive[q] = 0;  // matched or NaN: leaves the pool
+            }
+            const unsigned long long mask = __ballot(match);
+            if (match) members[cnt + __popcll(mask & pe::lanemask_lt())] = (unsigned short)q;
+            cnt += __popcll(mask);
+        }
+        __syncthreads();
+        const int piv_row = ord[pos];
+        const int m = cnt + 1;  // cluster = matches (sorted order) + pivot LAST
+        double out_score = gsc[pos];
+        double out_class = (double)a.classes[beg + piv_row];
+        double out_coord = 0.0;  // lanes 8..11 hold x1,y1,x2,y2
+        const int c4 = lane - 8;
+        if (cnt == 0) {
+            if (c4 >= 0 && c4 < 4) out_coord = a.boxes[(size_t)(beg + piv_row) * 4 + c4];
+        } else {
+            // ---------- score fusion ----------
+            if (L > 0) {
+                double s = 0.0;
+                if (lane < L) {
+                    double acc = 0.0;
+                    const double* col = glog + (size_t)lane * R;
+                    for (int t = 0; t < m; ++t) acc += col[t < cnt ? members[t] : pos];
+                    s = exp(acc);
+                }
+                double tot = 0.0;
+                for (int j = 0; j < L; ++j) tot += __shfl(s, j);
+                const double norm = s / tot;
+                if (a.score_mode == PE_SCORE_PROBEN) {
+                    // np.max / np.argmax over the K+1 entries INCLUDING background; NaN wins, first NaN index
+                    double best = __shfl(norm, 0);
+                    int bi = 0;
+                    bool bnan = best != best;
+                    for (int j = 1; j < L; ++j) {
+                        const double v = __shfl(norm, j);
+                        if (!bnan && (v != v || v > best)) { best = v; bi = j; bnan = v != v; }
+                    }
+                    out_score = best;
+                    out_class = (double)bi;
+                } else {
+                    out_score = __shfl(norm, 0);
+                }
+            } else if (a.score_mode == PE_SCORE_AVG) {
+                double acc = 0.0;
+                for (int t = 0; t < m; ++t) acc += gsc[t < cnt ? members[t] : pos];
+                out_score = acc / (double)m;
+            } else {  // PE_SCORE_MAX: max over the whole [m,K] probability matrix
+                double best = -INFINITY;
+                bool bnan = false;
+                for (int t = 0; t < m; ++t) {
+                    const int r = ord[t < cnt ? members[t] : pos];
+                    for (int j = 0; j < K; ++j) {
+                        const double v = a.probs[(size_t)(beg + r) * K + j];
+                        if (v != v) bnan = true;
+                        best = v > best ? v : best;
+                    }
+                }
+                out_score = bnan ? NAN : best;
+            }
+            // ---------- box fusion (lanes 8..11, one coordinate each) ----------
+            if (c4 >= 0 && c4 < 4) {
+                if (a.box_mode == PE_BOX_VAVG || a.box_mode == PE_BOX_SAVG) {
+                    double wsum = 0.0;
+                    for (int t = 0; t < m; ++t) {
+                        const int p = t < cnt ? members[t] : pos;
+                        wsum += (a.box_mode == PE_BOX_VAVG) ? 1.0 / a.vars[beg + ord[p]] : gsc[p];
+                    }
+                    double acc = 0.0;
+                    for (int t = 0; t < m; ++t) {
+                        const int p = t < cnt ? members[t] : pos;
+                        const int r = ord[p];
+                        const double w = (a.box_mode == PE_BOX_VAVG) ? 1.0 / a.vars[beg + r] : gsc[p];
+                        acc += a.boxes[(size_t)(beg + r) * 4 + c4] * (w / wsum);
+                    }
+                    out_coord = acc;
+                } else if (a.box_mode == PE_BOX_AVG) {
+                    double acc = 0.0;
+                    for (int t = 0; t < m; ++t) acc += a.boxes[(size_t)(beg + ord[t < cnt ? members[t] : pos]) * 4 + c4];
+                    out_coord = acc / (double)m;
+                } else {  // argmax: box of the first maximal score in cluster order
+                    int bp = cnt > 0 ? members[0] : pos;
+                    double best = gsc[bp];
+                    bool bnan = best != best;
+                    for (int t = 1; t < m; ++t) {
+                        const int p = t < cnt ? members[t] : pos;
+                        const double v = gsc[p];
+                        if (!bnan && (v != v || v > best)) { best = v; bp = p; bnan = v != v; }
+                    }
+                    out_coord = a.boxes[(size_t)(beg + ord[bp]) * 4 + c4];
+                }
+            }
+        }
+        const size_t o = (size_t)beg + m_out;
+        if (lane == 0) {
+            a.out_scores[o] = (float)out_score;
+            a.out_classes[o] = (float)out_class;
+            a.out_keep[o] = piv_row;
+        }
+        if (c4 >= 0 && c4 < 4) a.out_boxes[o * 4 + c4] = out_coord;
+        ++m_out;
+    }
+    if (lane == 0) a.out_counts[img] = m_out;
+}
+
+}  // namespace
+
+extern "C" int pe_proben_fuse_batch(const double* boxes, const double* scores, const double* probs,
+                                    const double* variances, const int32_t* classes, const int32_t* offsets,
+                                    int32_t num_images, int32_t num_classes, int32_t max_rows_per_image,
+                                    int32_t score_mode, int32_t box_mode, double iou_thresh, double frame_w,
+                                    double frame_h, double* out_boxes, float* out_scores, float* out_classes,
+                                    int32_t* out_keep, int32_t* out_counts, void* stream) {
+    PE_CHECK_ARG(num_images >= 0, "pe_proben_fuse_batch: num_images < 0");
+    if (num_images == 0) return PE_OK;
+    PE_CHECK_ARG(boxes && scores && variances && classes && offsets, "pe_proben_fuse_batch: null input pointer");
+    PE_CHECK_ARG(out_boxes && out_scores && out_classes && out_keep && out_counts,
+                 "pe_proben_fuse_batch: null output pointer");
+    PE_CHECK_ARG(score_mode >= 0 && score_mode <= 3, "pe_proben_fuse_batch: bad score_mode %d", score_mode);
+    PE_CHECK_ARG(box_mode >= 0 && box_mode <= 3, "pe_proben_fuse_batch: bad box_mode %d", box_mode);
+    PE_CHECK_ARG(num_classes >= 1 && num_classes <= 62, "pe_proben_fuse_batch: num_classes %d not in [1,62]",
+                 num_classes);
+    PE_CHECK_ARG(probs || (score_mode != PE_SCORE_PROBEN && score_mode != PE_SCORE_MAX),
+                 "pe_proben_fuse_batch: probs required for this score_mode");
+    PE_CHECK_ARG(max_rows_per_image >= 1 && max_rows_per_image <= 2048,
+                 "pe_proben_fuse_batch: max_rows_per_image %d not in [1,2048]", max_rows_per_image);
+    const int R = (max_rows_per_image + 1) & ~1;  // keep the int/short/byte carves 8-byte aligned
+    const int L = score_mode == PE_SCORE_PROBEN ? num_classes + 1 : (score_mode == PE_SCORE_PROBEN_BINARY ? 2 : 0);
+    const size_t lds = (size_t)R * (8 * (6 + L) + 4 + 2 + 1) + 16;
+    if (lds > 160 * 1024) {
+        pe::set_error("pe_proben_fuse_batch: %zu bytes of LDS needed (> 160 KiB); lower max_rows_per_image", lds);
+        return PE_ERR_UNSUPPORTED;
+    }
+    ProbenArgs a{boxes, scores, probs, variances, classes, offsets, num_images, num_classes, R,
+                 score_mode, box_mode, iou_thresh, frame_w, frame_h,
+                 out_boxes, out_scores, out_classes, out_keep, out_counts};
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(proben_fuse_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            pe::set_error("pe_proben_fuse_batch: cannot raise dynamic LDS to %zu: %s", lds, hipGetErrorString(e));
+            return PE_ERR_HIP;
+        }
+    }
+    hipLaunchKernelGGL(proben_fuse_kernel, dim3(num_images), dim3(64), lds, (hipStream_t)stream, a);
+    PE_CHECK_LAUNCH("pe_proben_fuse_batch");
+    return PE_OK;
+}

@@ -1,0 +1,116 @@
+"""ProbEn late fusion on the GPU - host side.
+
+Mirrors the reference's call surface (demo/FLIR/demo_probEn.py):
+  fusion(method, info_1, info_2, info_3='')   :189-196  (one image, Python lists in)
+and adds the batched form the MI355X path actually uses:
+  fuse_batch(...)                             one launch, one wavefront per image.
+The arithmetic lives in csrc/proben.hip behind pe_proben_fuse_batch.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+
+SCORE_MODES = {"probEn": 0, "avg": 1, "max": 2, "probEn_binary": 3}
+BOX_MODES = {"v-avg": 0, "s-avg": 1, "avg": 2, "argmax": 3}
+FRAME_W, FRAME_H = 640.0, 512.0  # class-band shift hard-coded by the reference (demo_probEn.py:100-103)
+
+
+def fuse_batch(boxes, scores, probs, variances, classes, offsets, score_fusion="probEn", box_fusion="v-avg",
+               max_rows=None, iou_thresh=0.5, frame=(FRAME_W, FRAME_H)):
+    """Fuse B images in one launch.
+
+    boxes f64 [Ntot,4], scores f64 [Ntot], probs f64 [Ntot,K], variances f64 [Ntot],
+    classes i32 [Ntot], offsets i32 [B+1] - all CUDA tensors, rows of each image already
+    concatenated in detector order.  Returns a dict of device tensors:
+      boxes f64 [Ntot,4], scores f32 [Ntot], classes f32 [Ntot], keep i32 [Ntot], counts i32 [B];
+    image b's fused rows are [offsets[b], offsets[b]+counts[b]).
+    """
+    _lib.require_cuda(boxes, scores, probs, variances, classes, offsets)
+    if score_fusion == "max" and box_fusion == "argmax":
+        raise ValueError("('max','argmax') is the class-aware NMS route: use fusion()/nms_fuse_batch")
+    B = offsets.numel() - 1
+    ntot = boxes.shape[0]
+    K = probs.shape[1] if probs is not None and probs.dim() == 2 else 1
+    boxes = boxes.contiguous().double()
+    scores = scores.contiguous().double()
+    probs = probs.contiguous().double() if probs is not None else None
+    variances = variances.reshape(-1).contiguous().double()
+    classes = classes.contiguous().to(torch.int32)
+    offsets = offsets.contiguous().to(torch.int32)
+    if max_rows is None:
+        max_rows = int((offsets[1:] - offsets[:-1]).max().item()) if B > 0 else 1
+    max_rows = max(int(max_rows), 1)
+    dev = boxes.device
+    out = {
+        "boxes": torch.empty((ntot, 4), dtype=torch.float64, device=dev),
+        "scores": torch.empty((ntot,), dtype=torch.float32, device=dev),
+        "classes": torch.empty((ntot,), dtype=torch.float32, device=dev),
+        "keep": torch.empty((ntot,), dtype=torch.int32, device=dev),
+        "counts": torch.zeros((max(B, 1),), dtype=torch.int32, device=dev)[:B],
+    }
+    st = _lib.lib().pe_proben_fuse_batch(
+        _lib.ptr(boxes), _lib.ptr(scores), _lib.ptr(probs), _lib.ptr(variances), _lib.ptr(classes),
+        _lib.ptr(offsets), B, K, max_rows, SCORE_MODES[score_fusion], BOX_MODES[box_fusion],
+        float(iou_thresh), float(frame[0]), float(frame[1]),
+        _lib.ptr(out["boxes"]), _lib.ptr(out["scores"]), _lib.ptr(out["classes"]), _lib.ptr(out["keep"]),
+        _lib.ptr(out["counts"]), _lib.stream())
+    _lib.check(st, "pe_proben_fuse_batch")
+    return out
+
+
+def pack_infos(per_image_infos, device="cuda"):
+    """per_image_infos: list (images) of lists (detectors) of reference-style dicts
+    {bbox, score, class, prob, vars}.  Returns the flat device tensors + offsets."""
+    bb, ss, cc, pp, vv, offs = [], [], [], [], [], [0]
+    K = None
+    for infos in per_image_infos:
+        for d in infos:
+            if d and len(d["prob"]) > 0:
+                K = len(d["prob"][0])
+                break
+        if K:
+            break
+    K = K or 3
+    for infos in per_image_infos:
+        n = 0
+        for d in infos:
+            if not d or len(d["bbox"]) == 0:
+                continue
+            bb.append(np.asarray(d["bbox"], dtype=np.float64).reshape(-1, 4))
+            ss.append(np.asarray(d["score"], dtype=np.float64).reshape(-1))
+            cc.append(np.asarray(d["class"], dtype=np.int32).reshape(-1))
+            pp.append(np.asarray(d["prob"], dtype=np.float64).reshape(-1, K))
+            vv.append(np.asarray(d["vars"], dtype=np.float64).reshape(-1))
+            n += len(ss[-1])
+        offs.append(offs[-1] + n)
+
+    def cat(xs, shape, dt):
+        return torch.from_numpy(np.concatenate(xs) if xs else np.zeros(shape, dtype=dt)).to(device)
+
+    return (cat(bb, (0, 4), np.float64), cat(ss, (0,), np.float64), cat(pp, (0, K), np.float64),
+            cat(vv, (0,), np.float64), cat(cc, (0,), np.int32),
+            torch.tensor(offs, dtype=torch.int32, device=device))
+
+
+def fusion(method, info_1, info_2, info_3=""):
+    """Drop-in for the reference's ``fusion`` (demo_probEn.py:189-196).
+
+    Returns (out_boxes, out_scores, out_class): boxes as a list of float64 ndarrays [4]
+    (or a float32 Tensor [n,4] on the ('max','argmax') route), scores / classes as float32
+    CPU tensors - the reference's return types."""
+    infos = [info_1, info_2] + ([info_3] if info_3 else [])
+    if method[0] == "max" and method[1] == "argmax":
+        from .layers import batched_nms
+        boxes = torch.tensor(sum([list(d["bbox"]) for d in infos], []), dtype=torch.float32).reshape(-1, 4)
+        scores = torch.tensor(sum([list(d["score"]) for d in infos], []), dtype=torch.float32)
+        classes = torch.tensor(sum([list(d["class"]) for d in infos], []), dtype=torch.float32)
+        keep = batched_nms(boxes.cuda(), scores.cuda(), classes.cuda(), 0.5).cpu()
+        return boxes[keep], scores[keep], classes[keep]
+    b, s, p, v, c, offs = pack_infos([infos])
+    out = fuse_batch(b, s, p, v, c, offs, method[0], method[1])
+    m = int(out["counts"][0].item())
+    if m < 0:
+        raise RuntimeError("fusion: too many rows for one image")
+    boxes = out["boxes"][:m].cpu().numpy()
+    return [boxes[i] for i in range(m)], out["scores"][:m].cpu(), out["classes"][:m].cpu()
