@@ -49,31 +49,8 @@ def test_hip_matches_reference_goldens(cases, sm, bm):
 
 
 def synth_batch(B, seed, kdet=2, nmax=100, K=3):
-    """BASELINE config-3 style synthetic detections: n ~ U{0..nmax} per detector,
-    30 % cross-detector near-duplicates, probs ~ Dirichlet(1,1,1,0.3)[:3] with max > 0.5."""
-    rng = np.random.default_rng(seed)
-    per_image = []
-    for _ in range(B):
-        infos, base = [], None
-        for d in range(kdet):
-            n = int(rng.integers(0, nmax + 1))
-            x1 = rng.uniform(0, 560, n); y1 = rng.uniform(0, 440, n)
-            bx = np.stack([x1, y1, np.minimum(x1 + rng.uniform(10, 160, n), 640),
-                           np.minimum(y1 + rng.uniform(10, 160, n), 512)], 1).reshape(n, 4)
-            if base is not None and len(base) and n:
-                dup = rng.random(n) < 0.3
-                src = base[rng.integers(0, len(base), n)]
-                bx[dup] = np.clip(src[dup] + rng.normal(0, 3, (int(dup.sum()), 4)), 0, [640, 512, 640, 512])
-            p = rng.dirichlet([1, 1, 1, 0.3], max(n, 1) * 4)[:, :K]
-            p = p[p.max(1) > 0.5][:n]
-            while len(p) < n:
-                p = np.concatenate([p, p])[:n]
-            f32 = lambda a: np.asarray(a, np.float32).astype(np.float64)  # noqa: E731
-            infos.append({"bbox": f32(bx), "score": f32(p.max(1)) if n else np.zeros(0), "class": p.argmax(1) if n else np.zeros(0, int),
-                          "prob": f32(p).reshape(n, K), "vars": f32(rng.uniform(0.5, 3, (n, 1)))})
-            base = bx if base is None else np.concatenate([base, bx])
-        per_image.append(infos)
-    return per_image
+    from proben_amd.synthetic import synth_detections
+    return synth_detections(B, seed, kdet=kdet, nmax=nmax, K=K)
 
 
 @pytest.mark.parametrize("sm,bm", [("probEn", "v-avg"), ("avg", "s-avg"), ("max", "avg"), ("probEn", "argmax")])
