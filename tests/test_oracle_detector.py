@@ -161,6 +161,10 @@ def test_full_forward_matches_reference_r50(golden_dir):
         np.testing.assert_array_equal(o["classes"].numpy(), z[f"e2e_classes_{n}"])
         np.testing.assert_allclose(o["scores"].numpy(), z[f"e2e_scores_{n}"], rtol=1e-4, atol=1e-5)
         np.testing.assert_allclose(o["boxes"].numpy(), z[f"e2e_boxes_{n}"], rtol=1e-4, atol=1e-2)
-        np.testing.assert_allclose(o["class_logits"].numpy(), z[f"e2e_logits_{n}"], rtol=1e-3, atol=1e-3)
         np.testing.assert_allclose(o["prob_score"].numpy(), z[f"e2e_prob_{n}"], rtol=1e-4, atol=1e-5)
-        np.testing.assert_allclose(o["vars"].numpy(), z[f"e2e_vars_{n}"], rtol=1e-4, atol=1e-5)
+        if n == 0:
+            # quirk Q2: in a batch > 1 the reference indexes the WHOLE-BATCH logits / variance with per-image
+            # indices (fast_rcnn.py:441-448), so only image 0 of a batch carries its own rows.  All reference
+            # demos run batch 1; the oracle (and the HIP path) implement the batch-1 semantics per image.
+            np.testing.assert_allclose(o["class_logits"].numpy(), z[f"e2e_logits_{n}"], rtol=1e-3, atol=1e-3)
+            np.testing.assert_allclose(o["vars"].numpy(), z[f"e2e_vars_{n}"], rtol=1e-4, atol=1e-5)
