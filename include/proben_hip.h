@@ -16,6 +16,7 @@
 #ifndef PROBEN_HIP_H
 #define PROBEN_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -69,6 +70,131 @@ int pe_proben_fuse_batch(const double* boxes,     /* [Ntot,4] xyxy */
                          int32_t* out_keep,              /* [Ntot] row index (image-local) of each pivot */
                          int32_t* out_counts,            /* [B] */
                          void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused convolution / GEMM: NHWC fp16 activations, [Cout][KH][KW][Cin] fp16 weights, fp32 accumulate
+ * on MFMA, epilogue = + bias[Cout] (fp32) + residual + ReLU, fp16 (or fp32) NHWC output.
+ * Replaces, per layer, detectron2.layers.Conv2d.forward (layers/wrappers.py:62-98) + FrozenBatchNorm2d
+ * (layers/batch_norm.py:45-65; folded into weight/bias by the caller) + relu_ + the residual add of
+ * BottleneckBlock.forward (modeling/backbone/resnet.py:205-221) + the nearest-2x top-down add of
+ * FPN.forward (modeling/backbone/fpn.py:129-137); with H = W = 1 it is the nn.Linear of
+ * FastRCNNConvFCHead / FastRCNNOutputLayers (roi_heads/box_head.py:73-81, fast_rcnn.py:531-545).
+ *   kernel 1: 1x1, stride 1|2, no padding, Cin % 64 == 0
+ *   kernel 3: 3x3, stride 1, padding 1, Cin % 64 == 0
+ *   kernel 7: the stem, 7x7 stride 2 padding 3 over an NHWC4 input; weight packed [Cout][8][8][4]
+ *             (kh 0..6 real + 1 zero row, kw 0..6 real + 1 zero column, 4 channels)
+ *   residual_mode 0: none; 1: residual has the output's shape; 2: residual is [N,res_h,res_w,Cout]
+ *             and is read at (oh/2, ow/2) (nearest-2x upsample).
+ *   out_f32 != 0: fp32 output, only channels [0, cout_store) are written, row stride out_stride.
+ * ------------------------------------------------------------------------------------------- */
+int pe_conv2d_nhwc_f16(const void* input, const void* weight, const float* bias, const void* residual,
+                       void* output, int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
+                       int32_t kernel, int32_t stride, int32_t relu, int32_t residual_mode,
+                       int32_t res_h, int32_t res_w, int32_t out_f32, int32_t cout_store,
+                       int32_t out_stride, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Front-end layout kernels.
+ * pe_preprocess_pack: one image -> normalised, zero-padded NHWC4 fp16 (optionally bilinear-resized first).
+ *   Replaces GeneralizedRCNN.preprocess_image (modeling/meta_arch/rcnn.py:269-286), ImageList.from_tensors
+ *   (structures/image_list.py:51-102) and, when dst size != src size, ResizeTransform.apply_image
+ *   (data/transforms/transform.py:81-98; half-pixel bilinear, uint8 sources rounded back to integers -
+ *   parity with PIL / cv2 resampling is unpinned).
+ *   src_kind 0: HWC uint8, 1: HWC float32, 2: CHW float32.  Source channels [ch0, ch0+nch) -> output
+ *   channels 0..nch-1 (flip_rgb reverses the first three); mean/std are HOST arrays of length nch.
+ * pe_maxpool3x3s2_nhwc: F.max_pool2d(x, 3, 2, 1) of BasicStem.forward (modeling/backbone/resnet.py:383).
+ * pe_subsample2_nhwc:   LastLevelMaxPool (modeling/backbone/fpn.py:166-178) = x[:, ::2, ::2].
+ * ------------------------------------------------------------------------------------------- */
+int pe_preprocess_pack(const void* src, int32_t src_kind, int32_t src_h, int32_t src_w, int32_t src_c,
+                       int32_t ch0, int32_t nch, int32_t flip_rgb, int32_t dst_h, int32_t dst_w,
+                       int32_t pad_h, int32_t pad_w, const float* mean_host, const float* std_host,
+                       void* dst, void* stream);
+int pe_maxpool3x3s2_nhwc(const void* in, void* out, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
+int pe_subsample2_nhwc(const void* in, void* out, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Batched class-aware greedy NMS (float32).  Replaces detectron2.layers.batched_nms
+ * (layers/nms.py:20-37) -> torchvision.ops.boxes.batched_nms / nms (torchvision 0.13.0), call sites
+ * proposal_generator/rpn_outputs.py:147, roi_heads/fast_rcnn.py:130, demo/FLIR/demo_probEn.py:64.
+ *   boxes [B,n_max,4], scores [B,n_max], idxs [B,n_max] (class / level id, may be NULL),
+ *   counts [B] rows used per image (NULL = n_max), valid [B,n_max] optional row mask.
+ *   mode 0: coordinate trick (boxes + idx*(max+1)), mode 1: suppress only within equal idx ("vanilla").
+ *   out_keep [B,max_out] input-row indices in score-descending order (ties: lower index first),
+ *   out_counts [B].  scratch: pe_nms_scratch_bytes(B, n_max) bytes of device memory.
+ * ------------------------------------------------------------------------------------------- */
+#define PE_NMS_TRICK 0
+#define PE_NMS_CLASS 1
+size_t pe_nms_scratch_bytes(int32_t B, int32_t n_max);
+int pe_nms_batched(const float* boxes, const float* scores, const int32_t* idxs, const int32_t* counts,
+                   const uint8_t* valid, int32_t B, int32_t n_max, float iou_thresh, int32_t mode,
+                   int32_t max_out, int32_t* out_keep, int32_t* out_counts, void* scratch,
+                   size_t scratch_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * RPN proposal selection: per (image, level) top-k of the objectness logits, decode of the survivors
+ * against analytically generated anchors, finite / clip-to-unpadded-size / non-empty flags.
+ * Replaces DefaultAnchorGenerator (modeling/anchor_generator.py:43-56,130-199), RPNOutputs.predict_proposals
+ * / predict_objectness_logits (proposal_generator/rpn_outputs.py:409-452), Box2BoxTransform.apply_deltas
+ * (box_regression.py:73-110) and find_top_rpn_proposals' selection half (rpn_outputs.py:100-145).
+ *   level_heads_host[l]: DEVICE pointer to the fused RPN head output of level l, fp32 [N*H*W, head_stride]
+ *     (columns 0..2 objectness for anchors a=0..2, columns 3+4a..6+4a the deltas of anchor a);
+ *   level_hw_host [L,2], level_stride_host [L], cell_anchors_host [L,3,4] are HOST arrays;
+ *   image_hw [N,2] device int32 (h,w) of the unpadded resized images;
+ *   outputs per image: cand_per_image = sum_l min(pre_nms_topk, H*W*3) rows, level-major, each level
+ *   sorted by logit descending (ties: anchor index ascending).
+ * pe_gather_boxes: rows keep[n, :counts[n]] of boxes/scores -> dense [N,max_out,...], zero padded.
+ * ------------------------------------------------------------------------------------------- */
+int pe_rpn_select_topk(const float* const* level_heads_host, const int32_t* level_hw_host,
+                       const int32_t* level_stride_host, const float* cell_anchors_host,
+                       int32_t num_levels, int32_t N, int32_t head_stride, int32_t pre_nms_topk,
+                       const int32_t* image_hw, float scale_clamp, float* cand_boxes, float* cand_scores,
+                       int32_t* cand_level, uint8_t* cand_valid, int32_t cand_per_image, void* stream);
+int pe_gather_boxes(const float* boxes, const float* scores, const int32_t* keep, const int32_t* counts,
+                    int32_t N, int32_t n_in, int32_t max_out, float* out_boxes, float* out_scores,
+                    void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * ROIAlign forward over NHWC feature maps.  Replaces roi_align_forward of detectron2._C
+ * (layers/csrc/ROIAlign/ROIAlign.h:54-84, ROIAlign_cuda.cu:12-139,310-366; same arithmetic as
+ * ROIAlign_cpu.cpp:22-218) and, with num_levels == 4, ROIPooler.forward + assign_boxes_to_levels
+ * (modeling/poolers.py:13-44,180-235) in one launch.
+ *   feats_host[l]: DEVICE pointers, feature l is [N, H_l, W_l, C]; dtype 0 = fp16, 1 = fp32 (in and out);
+ *   rois: [R,5] (batch,x1,y1,x2,y2) when rois_have_batch_index, else boxes [N, per_image, 4] with
+ *         counts[n] live rows per image (dead rows produce zeros);
+ *   output [R, pooled_h, pooled_w, C]; out_level (optional) [R] assigned level or -1.
+ * ------------------------------------------------------------------------------------------- */
+int pe_roi_align_nhwc(const void* const* feats_host, const int32_t* feat_hw_host, const float* scales_host,
+                      int32_t num_levels, int32_t N, int32_t C, int32_t dtype, const float* rois,
+                      int32_t rois_have_batch_index, int32_t num_rois, int32_t per_image,
+                      const int32_t* counts, int32_t pooled_h, int32_t pooled_w, int32_t sampling_ratio,
+                      int32_t aligned, void* output, int32_t* out_level, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Box-head post-processing.  Replaces FastRCNNOutputs.inference / fast_rcnn_inference_single_image
+ * (modeling/roi_heads/fast_rcnn.py:43-147,345-360,417-452) and detector_postprocess
+ * (modeling/postprocessing.py:8-38).  head: fp32 [N*per_image, head_stride] with columns
+ * [0,K] logits, [K+1,5K] deltas (class-major), 5K+1 log-variance.
+ *   pe_boxhead_candidates: softmax, decode (weights reg_weights_host[4]), finite mask, clip to image_hw,
+ *     score > thresh -> candidates in (row, class) order: boxes, scores, class, (filtered row, original row).
+ *   (caller runs pe_nms_batched over the candidates, class-aware, max_out = max_det)
+ *   pe_boxhead_finalize: gathers the kept candidates' fields (incl. the reference's Q3/Q4 index quirks;
+ *     fix_vars != 0 pairs each detection with its own proposal's variance), rescales to out_hw, clips,
+ *     drops empty boxes.
+ * ------------------------------------------------------------------------------------------- */
+int pe_boxhead_candidates(const float* head, int32_t head_stride, int32_t N, int32_t per_image,
+                          int32_t num_classes, const int32_t* prop_counts, const float* proposals,
+                          const int32_t* image_hw, const float* reg_weights_host, float scale_clamp,
+                          float score_thresh, int32_t cand_max, float* cand_boxes, float* cand_scores,
+                          int32_t* cand_class, int32_t* cand_rows, int32_t* cand_counts, float* probs,
+                          void* stream);
+int pe_boxhead_finalize(const float* head, int32_t head_stride, int32_t N, int32_t per_image,
+                        int32_t num_classes, int32_t cand_max, int32_t max_det, int32_t fix_vars,
+                        const float* probs, const float* cand_boxes, const float* cand_scores,
+                        const int32_t* cand_class, const int32_t* cand_rows, const int32_t* keep,
+                        const int32_t* keep_counts, const int32_t* image_hw, const int32_t* out_hw,
+                        float* det_boxes, float* det_scores, int32_t* det_classes, float* det_logits,
+                        float* det_probs, float* det_vars, int32_t* det_rows, int32_t* det_counts,
+                        void* stream);
 
 #ifdef __cplusplus
 }

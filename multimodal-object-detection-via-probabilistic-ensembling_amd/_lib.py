@@ -9,13 +9,25 @@ LIB_PATH = os.path.join(_PKG, "libproben_hip.so")
 _lib = None
 
 c_void_p, c_int, c_double, c_float = ctypes.c_void_p, ctypes.c_int32, ctypes.c_double, ctypes.c_float
+c_size_t = ctypes.c_size_t
 
 # name -> argtypes (restype is always int unless listed in _RESTYPE)
 SIGNATURES = {
     "pe_version": [],
     "pe_proben_fuse_batch": [c_void_p] * 6 + [c_int] * 5 + [c_double] * 3 + [c_void_p] * 5 + [c_void_p],
+    "pe_conv2d_nhwc_f16": [c_void_p] * 5 + [c_int] * 14 + [c_void_p],
+    "pe_preprocess_pack": [c_void_p] + [c_int] * 11 + [c_void_p] * 4,
+    "pe_maxpool3x3s2_nhwc": [c_void_p] * 2 + [c_int] * 4 + [c_void_p],
+    "pe_subsample2_nhwc": [c_void_p] * 2 + [c_int] * 4 + [c_void_p],
+    "pe_nms_scratch_bytes": [c_int, c_int],
+    "pe_nms_batched": [c_void_p] * 5 + [c_int, c_int, c_float, c_int, c_int] + [c_void_p] * 3 + [c_size_t, c_void_p],
+    "pe_rpn_select_topk": [c_void_p] * 4 + [c_int] * 4 + [c_void_p, c_float] + [c_void_p] * 4 + [c_int, c_void_p],
+    "pe_gather_boxes": [c_void_p] * 4 + [c_int] * 3 + [c_void_p] * 3,
+    "pe_roi_align_nhwc": [c_void_p] * 3 + [c_int] * 4 + [c_void_p] + [c_int] * 3 + [c_void_p] + [c_int] * 4 + [c_void_p] * 3,
+    "pe_boxhead_candidates": [c_void_p, c_int, c_int, c_int, c_int] + [c_void_p] * 4 + [c_float, c_float, c_int] + [c_void_p] * 7,
+    "pe_boxhead_finalize": [c_void_p] + [c_int] * 7 + [c_void_p] * 18,
 }
-_RESTYPE = {"pe_last_error": ctypes.c_char_p}
+_RESTYPE = {"pe_last_error": ctypes.c_char_p, "pe_nms_scratch_bytes": ctypes.c_size_t}
 
 
 class HipLibraryError(RuntimeError):
@@ -36,7 +48,7 @@ def lib():
         for name, args in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError here = header/library mismatch
             fn.argtypes = args
-            fn.restype = ctypes.c_int
+            fn.restype = _RESTYPE.get(name, ctypes.c_int)
         _lib = L
     return _lib
 

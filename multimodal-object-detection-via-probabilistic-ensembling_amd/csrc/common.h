@@ -5,6 +5,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
+
 #include "proben_hip.h"
 
 namespace pe {

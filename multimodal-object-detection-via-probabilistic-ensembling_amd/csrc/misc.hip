@@ -1,0 +1,155 @@
+// Small HBM-bound layout / pooling kernels of the detector front end (gfx950).
+//   pe_preprocess_pack   : resize (optional) + normalise + zero-pad + NHWC4 fp16 pack of one image
+//                          (GeneralizedRCNN.preprocess_image meta_arch/rcnn.py:269-286,
+//                           ImageList.from_tensors structures/image_list.py:51-102,
+//                           ResizeShortestEdge/ResizeTransform data/transforms/transform.py:81-98)
+//   pe_maxpool3x3s2_nhwc : the stem's max_pool2d(3, 2, 1) (backbone/resnet.py:383)
+//   pe_subsample2_nhwc   : LastLevelMaxPool = max_pool2d(k=1, s=2) = x[:, ::2, ::2] (backbone/fpn.py:166-178)
+#include <hip/hip_fp16.h>
+
+#include "common.h"
+
+namespace {
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+
+struct PackArgs {
+    const void* src;  // HWC uint8 / HWC float32 / CHW float32
+    int src_kind;     // 0: HWC u8, 1: HWC f32, 2: CHW f32
+    int src_h, src_w, src_c;
+    int ch0, nch;     // channels [ch0, ch0+nch) of the source feed output channels 0..nch-1 (nch <= 4)
+    int flip_rgb;     // reverse the first 3 selected channels (RGB <-> BGR, engine/defaults.py:188-190)
+    int dst_h, dst_w;  // resized size (== src size when no resize)
+    int pad_h, pad_w;  // padded size (multiple of 32)
+    float mean[4], inv_std[4];
+    _Float16* dst;  // [pad_h, pad_w, 4]
+};
+
+__device__ __forceinline__ float src_at(const PackArgs& a, int y, int x, int c) {
+    if (a.src_kind == 0) return (float)reinterpret_cast<const unsigned char*>(a.src)[((size_t)y * a.src_w + x) * a.src_c + c];
+    if (a.src_kind == 1) return reinterpret_cast<const float*>(a.src)[((size_t)y * a.src_w + x) * a.src_c + c];
+    return reinterpret_cast<const float*>(a.src)[((size_t)c * a.src_h + y) * a.src_w + x];
+}
+
+__global__ void preprocess_pack_kernel(PackArgs a) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= a.pad_w) return;
+    half4 o = {0, 0, 0, 0};
+    if (y < a.dst_h && x < a.dst_w) {
+        const bool resize = a.dst_h != a.src_h || a.dst_w != a.src_w;
+        float sy = 0.f, sx = 0.f;
+        int y0 = y, x0 = x, y1 = y, x1 = x;
+        if (resize) {  // bilinear, half-pixel centres, edge clamp
+            sy = ((float)y + 0.5f) * ((float)a.src_h / (float)a.dst_h) - 0.5f;
+            sx = ((float)x + 0.5f) * ((float)a.src_w / (float)a.dst_w) - 0.5f;
+            sy = fminf(fmaxf(sy, 0.f), (float)(a.src_h - 1));
+            sx = fminf(fmaxf(sx, 0.f), (float)(a.src_w - 1));
+            y0 = (int)sy; x0 = (int)sx;
+            y1 = min(y0 + 1, a.src_h - 1); x1 = min(x0 + 1, a.src_w - 1);
+            sy -= (float)y0; sx -= (float)x0;
+        }
+        for (int c = 0; c < a.nch; ++c) {
+            const int sc = a.ch0 + ((a.flip_rgb && c < 3) ? 2 - c : c);
+            float v;
+            if (resize) {
+                const float top = src_at(a, y0, x0, sc) * (1.f - sx) + src_at(a, y0, x1, sc) * sx;
+                const float bot = src_at(a, y1, x0, sc) * (1.f - sx) + src_at(a, y1, x1, sc) * sx;
+                v = top * (1.f - sy) + bot * sy;
+                if (a.src_kind == 0) v = rintf(v);  // the reference resizes uint8 images to uint8
+            } else {
+                v = src_at(a, y, x, sc);
+            }
+            o[c] = (_Float16)((v - a.mean[c]) * a.inv_std[c]);
+        }
+    }
+    *reinterpret_cast<half4*>(a.dst + ((size_t)y * a.pad_w + x) * 4) = o;
+}
+
+__global__ void maxpool3x3s2_kernel(const _Float16* in, _Float16* out, int N, int H, int W, int C, int Ho, int Wo) {
+    const int cv = C / 8;
+    const size_t total = (size_t)N * Ho * Wo * cv;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c8 = (int)(i % cv);
+        size_t t = i / cv;
+        const int ow = (int)(t % Wo); t /= Wo;
+        const int oh = (int)(t % Ho);
+        const int n = (int)(t / Ho);
+        float m[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = -INFINITY;
+        for (int kh = 0; kh < 3; ++kh) {
+            const int ih = oh * 2 - 1 + kh;
+            if ((unsigned)ih >= (unsigned)H) continue;
+            for (int kw = 0; kw < 3; ++kw) {
+                const int iw = ow * 2 - 1 + kw;
+                if ((unsigned)iw >= (unsigned)W) continue;
+                const half8 v = *reinterpret_cast<const half8*>(in + (((size_t)n * H + ih) * W + iw) * C + c8 * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], (float)v[e]);
+            }
+        }
+        half8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (_Float16)m[e];
+        *reinterpret_cast<half8*>(out + i * 8) = o;
+    }
+}
+
+__global__ void subsample2_kernel(const _Float16* in, _Float16* out, int N, int H, int W, int C, int Ho, int Wo) {
+    const int cv = C / 8;
+    const size_t total = (size_t)N * Ho * Wo * cv;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c8 = (int)(i % cv);
+        size_t t = i / cv;
+        const int ow = (int)(t % Wo); t /= Wo;
+        const int oh = (int)(t % Ho);
+        const int n = (int)(t / Ho);
+        *reinterpret_cast<half8*>(out + i * 8) =
+            *reinterpret_cast<const half8*>(in + (((size_t)n * H + oh * 2) * W + ow * 2) * C + c8 * 8);
+    }
+}
+}  // namespace
+
+extern "C" int pe_preprocess_pack(const void* src, int32_t src_kind, int32_t src_h, int32_t src_w, int32_t src_c,
+                                  int32_t ch0, int32_t nch, int32_t flip_rgb, int32_t dst_h, int32_t dst_w,
+                                  int32_t pad_h, int32_t pad_w, const float* mean_host, const float* std_host,
+                                  void* dst, void* stream) {
+    PE_CHECK_ARG(src && dst && mean_host && std_host, "pe_preprocess_pack: null pointer");
+    PE_CHECK_ARG(src_kind >= 0 && src_kind <= 2, "pe_preprocess_pack: src_kind %d", src_kind);
+    PE_CHECK_ARG(nch >= 1 && nch <= 4 && ch0 >= 0 && ch0 + nch <= src_c, "pe_preprocess_pack: channel window [%d,%d) of %d",
+                 ch0, ch0 + nch, src_c);
+    PE_CHECK_ARG(dst_h <= pad_h && dst_w <= pad_w && dst_h > 0 && dst_w > 0, "pe_preprocess_pack: bad sizes");
+    PackArgs a{};
+    a.src = src; a.src_kind = src_kind; a.src_h = src_h; a.src_w = src_w; a.src_c = src_c; a.ch0 = ch0; a.nch = nch;
+    a.flip_rgb = flip_rgb; a.dst_h = dst_h; a.dst_w = dst_w; a.pad_h = pad_h; a.pad_w = pad_w; a.dst = (_Float16*)dst;
+    for (int c = 0; c < 4; ++c) {
+        a.mean[c] = c < nch ? mean_host[c] : 0.f;
+        a.inv_std[c] = c < nch ? 1.f / std_host[c] : 0.f;
+    }
+    hipLaunchKernelGGL(preprocess_pack_kernel, dim3(pe::ceil_div(pad_w, 256), pad_h), dim3(256), 0, (hipStream_t)stream, a);
+    PE_CHECK_LAUNCH("pe_preprocess_pack");
+    return PE_OK;
+}
+
+extern "C" int pe_maxpool3x3s2_nhwc(const void* in, void* out, int32_t N, int32_t H, int32_t W, int32_t C, void* stream) {
+    PE_CHECK_ARG(in && out && C % 8 == 0, "pe_maxpool3x3s2_nhwc: bad args (C %% 8 == 0 required)");
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const size_t total = (size_t)N * Ho * Wo * (C / 8);
+    const int grid = (int)std::min<size_t>((total + 255) / 256, 256 * 32);
+    hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const _Float16*)in,
+                       (_Float16*)out, N, H, W, C, Ho, Wo);
+    PE_CHECK_LAUNCH("pe_maxpool3x3s2_nhwc");
+    return PE_OK;
+}
+
+extern "C" int pe_subsample2_nhwc(const void* in, void* out, int32_t N, int32_t H, int32_t W, int32_t C, void* stream) {
+    PE_CHECK_ARG(in && out && C % 8 == 0, "pe_subsample2_nhwc: bad args (C %% 8 == 0 required)");
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const size_t total = (size_t)N * Ho * Wo * (C / 8);
+    const int grid = (int)std::min<size_t>((total + 255) / 256, 256 * 32);
+    hipLaunchKernelGGL(subsample2_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const _Float16*)in,
+                       (_Float16*)out, N, H, W, C, Ho, Wo);
+    PE_CHECK_LAUNCH("pe_subsample2_nhwc");
+    return PE_OK;
+}

@@ -1,0 +1,179 @@
+// ROIAlign (aligned = True / False, adaptive sampling) over NHWC feature maps for gfx950: all FPN levels
+// in ONE launch, level assignment fused, no device synchronisation.
+//
+// Replaces ROIAlign_forward_cuda / RoIAlignForward (layers/csrc/ROIAlign/ROIAlign_cuda.cu:12-139,310-366;
+// arithmetic identical to ROIAlign_cpu.cpp:22-218), the autograd wrapper layers/roi_align.py:10-49, and
+// ROIPooler.forward + assign_boxes_to_levels + convert_boxes_to_pooler_format (modeling/poolers.py:13-81,180-235)
+// - i.e. 4 nonzero + 4 index_put + 4 launches + 4 cudaDeviceSynchronize per forward in the reference.
+//
+// The reference's CUDA kernel is one thread per output element over NCHW (uncoalesced).  Here features are
+// NHWC: one block per ROI, a thread owns a vector of VEC consecutive channels of one output bin, so every
+// bilinear tap is a coalesced 16-byte (fp16 x8) / 16-byte (fp32 x4) load shared by a wavefront's lanes.
+// Per sample the 4 taps are combined in the reference's order (w1*v1 + w2*v2 + w3*v3 + w4*v4, then
+// accumulated, then divided by the sample count) so fp32 results are bit-identical to the CPU kernel.
+// Output layout: [R, ph, pw, C] (the box head's fc1 weight is permuted to match at load time).
+#include <hip/hip_fp16.h>
+
+#include "common.h"
+
+namespace {
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+
+struct RoiArgs {
+    const void* feat[4];
+    int fh[4], fw[4];
+    float scale[4];
+    int num_levels;      // 1: single level (generic op); 4: FPN p2..p5 with level assignment
+    int N, C;
+    const float* rois;   // [R, 5] (batch, x1, y1, x2, y2)  or  [N, per_image, 4] boxes when rois5 == 0
+    int rois5, per_image;
+    const int32_t* counts;  // [N] valid boxes per image (boxes mode), may be null
+    int R;
+    int ph, pw, sampling_ratio, aligned;
+    int min_level, max_level, canonical_level;
+    float canonical_size;
+    void* out;           // [R, ph, pw, C]
+    int32_t* out_level;  // optional [R]
+};
+
+template <typename T>
+struct Vec;
+template <>
+struct Vec<_Float16> {
+    static constexpr int N = 8;
+    __device__ static void load(const _Float16* p, float* v) {
+        const half8 h = *reinterpret_cast<const half8*>(p);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (float)h[e];
+    }
+    __device__ static void store(_Float16* p, const float* v) {
+        half8 h;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) h[e] = (_Float16)v[e];
+        *reinterpret_cast<half8*>(p) = h;
+    }
+};
+template <>
+struct Vec<float> {
+    static constexpr int N = 4;
+    __device__ static void load(const float* p, float* v) {
+        const float4v h = *reinterpret_cast<const float4v*>(p);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = h[e];
+    }
+    __device__ static void store(float* p, const float* v) {
+        float4v h = {v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<float4v*>(p) = h;
+    }
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void roi_align_kernel(RoiArgs a) {
+    constexpr int V = Vec<T>::N;
+    const int r = blockIdx.x;
+    int b;
+    float bx1, by1, bx2, by2;
+    bool live = true;
+    if (a.rois5) {
+        const float* p = a.rois + (size_t)r * 5;
+        b = (int)p[0]; bx1 = p[1]; by1 = p[2]; bx2 = p[3]; by2 = p[4];
+    } else {
+        b = r / a.per_image;
+        const float* p = a.rois + (size_t)r * 4;
+        bx1 = p[0]; by1 = p[1]; bx2 = p[2]; by2 = p[3];
+        if (a.counts && (r - b * a.per_image) >= a.counts[b]) live = false;  // padded slot -> zeros
+    }
+    int lvl = 0;
+    if (a.num_levels > 1) {
+        // assign_boxes_to_levels (poolers.py:13-44): floor(canonical_level + log2(sqrt(area)/224 + eps))
+        const float area = (bx2 - bx1) * (by2 - by1);
+        const float sz = sqrtf(area);
+        float lv = floorf((float)a.canonical_level + log2f(sz / a.canonical_size + 2.220446049250313e-16f));
+        lv = fminf(fmaxf(lv, (float)a.min_level), (float)a.max_level);
+        lvl = (int)lv - a.min_level;
+    }
+    if (a.out_level && threadIdx.x == 0) a.out_level[r] = live ? lvl : -1;
+    const int H = a.fh[lvl], W = a.fw[lvl];
+    const float scale = a.scale[lvl];
+    const T* feat = reinterpret_cast<const T*>(a.feat[lvl]) + (size_t)b * H * W * a.C;
+    const float offset = a.aligned ? 0.5f : 0.0f;
+    const float start_w = bx1 * scale - offset, start_h = by1 * scale - offset;
+    const float end_w = bx2 * scale - offset, end_h = by2 * scale - offset;
+    float roi_w = end_w - start_w, roi_h = end_h - start_h;
+    if (!a.aligned) { roi_w = fmaxf(roi_w, 1.f); roi_h = fmaxf(roi_h, 1.f); }
+    const float bin_h = roi_h / (float)a.ph, bin_w = roi_w / (float)a.pw;
+    const int grid_h = a.sampling_ratio > 0 ? a.sampling_ratio : (int)ceilf(roi_h / (float)a.ph);
+    const int grid_w = a.sampling_ratio > 0 ? a.sampling_ratio : (int)ceilf(roi_w / (float)a.pw);
+    const float count = (float)max(grid_h * grid_w, 1);
+    const int cvec = a.C / V;
+    const int items = a.ph * a.pw * cvec;
+    T* out = reinterpret_cast<T*>(a.out) + (size_t)r * a.ph * a.pw * a.C;
+    for (int it = threadIdx.x; it < items; it += blockDim.x) {
+        const int cv = it % cvec, bin = it / cvec;
+        const int ph = bin / a.pw, pw = bin - ph * a.pw;
+        float acc[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[e] = 0.f;
+        if (live) {
+            for (int iy = 0; iy < grid_h; ++iy) {
+                const float yy = start_h + ph * bin_h + (float)(iy + .5f) * bin_h / (float)grid_h;
+                for (int ix = 0; ix < grid_w; ++ix) {
+                    const float xx = start_w + pw * bin_w + (float)(ix + .5f) * bin_w / (float)grid_w;
+                    float x = xx, y = yy;
+                    if (y < -1.0f || y > (float)H || x < -1.0f || x > (float)W) continue;
+                    if (y <= 0) y = 0;
+                    if (x <= 0) x = 0;
+                    int y_low = (int)y, x_low = (int)x, y_high, x_high;
+                    if (y_low >= H - 1) { y_high = y_low = H - 1; y = (float)y_low; } else y_high = y_low + 1;
+                    if (x_low >= W - 1) { x_high = x_low = W - 1; x = (float)x_low; } else x_high = x_low + 1;
+                    const float ly = y - y_low, lx = x - x_low, hy = 1.f - ly, hx = 1.f - lx;
+                    const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+                    float v1[V], v2[V], v3[V], v4[V];
+                    Vec<T>::load(feat + ((size_t)y_low * W + x_low) * a.C + cv * V, v1);
+                    Vec<T>::load(feat + ((size_t)y_low * W + x_high) * a.C + cv * V, v2);
+                    Vec<T>::load(feat + ((size_t)y_high * W + x_low) * a.C + cv * V, v3);
+                    Vec<T>::load(feat + ((size_t)y_high * W + x_high) * a.C + cv * V, v4);
+#pragma unroll
+                    for (int e = 0; e < V; ++e) acc[e] += w1 * v1[e] + w2 * v2[e] + w3 * v3[e] + w4 * v4[e];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < V; ++e) acc[e] /= count;
+        }
+        Vec<T>::store(out + (size_t)bin * a.C + cv * V, acc);
+    }
+}
+}  // namespace
+
+extern "C" int pe_roi_align_nhwc(const void* const* feats_host, const int32_t* feat_hw_host, const float* scales_host,
+                                 int32_t num_levels, int32_t N, int32_t C, int32_t dtype, const float* rois,
+                                 int32_t rois_have_batch_index, int32_t num_rois, int32_t per_image,
+                                 const int32_t* counts, int32_t pooled_h, int32_t pooled_w, int32_t sampling_ratio,
+                                 int32_t aligned, void* output, int32_t* out_level, void* stream) {
+    PE_CHECK_ARG(num_levels == 1 || num_levels == 4, "pe_roi_align_nhwc: num_levels %d not in {1,4}", num_levels);
+    PE_CHECK_ARG(dtype == 0 || dtype == 1, "pe_roi_align_nhwc: dtype %d (0 = fp16, 1 = fp32)", dtype);
+    PE_CHECK_ARG(feats_host && feat_hw_host && scales_host, "pe_roi_align_nhwc: null level tables");
+    PE_CHECK_ARG(C % (dtype == 0 ? 8 : 4) == 0, "pe_roi_align_nhwc: C %d not a multiple of the vector width", C);
+    PE_CHECK_ARG(pooled_h > 0 && pooled_w > 0, "pe_roi_align_nhwc: bad pooled size");
+    if (num_rois == 0) return PE_OK;  // empty in -> empty out, no launch (ROIAlign_cuda.cu:343-346)
+    PE_CHECK_ARG(rois && output, "pe_roi_align_nhwc: null pointer");
+    PE_CHECK_ARG(rois_have_batch_index || per_image > 0, "pe_roi_align_nhwc: per_image required in boxes mode");
+    RoiArgs a{};
+    for (int l = 0; l < num_levels; ++l) {
+        a.feat[l] = feats_host[l]; a.fh[l] = feat_hw_host[2 * l]; a.fw[l] = feat_hw_host[2 * l + 1];
+        a.scale[l] = scales_host[l];
+        PE_CHECK_ARG(a.feat[l] != nullptr, "pe_roi_align_nhwc: null feature pointer");
+    }
+    a.num_levels = num_levels; a.N = N; a.C = C; a.rois = rois; a.rois5 = rois_have_batch_index;
+    a.per_image = per_image; a.counts = counts; a.R = num_rois; a.ph = pooled_h; a.pw = pooled_w;
+    a.sampling_ratio = sampling_ratio; a.aligned = aligned;
+    a.min_level = 2; a.max_level = 5; a.canonical_level = 4; a.canonical_size = 224.f;
+    a.out = output; a.out_level = out_level;
+    if (dtype == 0)
+        hipLaunchKernelGGL(roi_align_kernel<_Float16>, dim3(num_rois), dim3(256), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(roi_align_kernel<float>, dim3(num_rois), dim3(256), 0, (hipStream_t)stream, a);
+    PE_CHECK_LAUNCH("pe_roi_align_nhwc");
+    return PE_OK;
+}

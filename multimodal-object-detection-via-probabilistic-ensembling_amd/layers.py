@@ -1,0 +1,188 @@
+"""Python op surface kept drop-in with the reference's `detectron2.layers`
+(batched_nms: layers/nms.py:20-37, ROIAlign: layers/roi_align.py:51-96) plus thin typed
+wrappers over the C-ABI kernels used by the detector.  No CPU fallbacks."""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+_scratch = {}
+
+
+def _get_scratch(nbytes, device):
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    buf = _scratch.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes * 1.25) + 1024, dtype=torch.uint8, device=device)
+        _scratch[key] = buf
+    return buf
+
+
+# ------------------------------------------------------------------------------------------------
+# NMS
+# ------------------------------------------------------------------------------------------------
+def nms_batched_raw(boxes, scores, idxs, counts, valid, iou_threshold, mode, max_out):
+    """boxes [B,n,4] f32, scores [B,n] f32, idxs [B,n] i32|None, counts [B] i32|None, valid [B,n] u8|None.
+    Returns keep [B,max_out] i32 (input row ids, score-descending), keep_counts [B] i32."""
+    _lib.require_cuda(boxes, scores)
+    B, n = scores.shape
+    dev = boxes.device
+    keep = torch.empty((B, max_out), dtype=torch.int32, device=dev)
+    kcnt = torch.zeros((B,), dtype=torch.int32, device=dev)
+    if B == 0:
+        return keep, kcnt
+    L = _lib.lib()
+    nbytes = L.pe_nms_scratch_bytes(B, max(n, 1))
+    scratch = _get_scratch(nbytes, dev)
+    st = L.pe_nms_batched(_lib.ptr(boxes), _lib.ptr(scores), _lib.ptr(idxs), _lib.ptr(counts), _lib.ptr(valid),
+                          B, n, float(iou_threshold), int(mode), int(max_out), _lib.ptr(keep), _lib.ptr(kcnt),
+                          _lib.ptr(scratch), scratch.numel(), _lib.stream())
+    _lib.check(st, "pe_nms_batched")
+    return keep, kcnt
+
+
+def batched_nms(boxes, scores, idxs, iou_threshold):
+    """Drop-in for detectron2.layers.batched_nms (layers/nms.py:20-37): boxes [N,4], scores [N],
+    idxs [N] -> int64 keep indices sorted by score descending.  torchvision's dispatch rule is kept:
+    coordinate trick up to 20000 box elements on a GPU, one NMS per class beyond that."""
+    assert boxes.shape[-1] == 4
+    _lib.require_cuda(boxes, scores, idxs)
+    n = boxes.shape[0]
+    if n == 0:
+        return torch.empty((0,), dtype=torch.int64, device=boxes.device)
+    mode = 1 if boxes.numel() > 20000 else 0
+    b = boxes.detach().float().contiguous().view(1, n, 4)
+    s = scores.detach().float().contiguous().view(1, n)
+    # class ids may arrive as float tensors (demo_probEn.py:57): torchvision does idxs.to(boxes)
+    i = idxs.detach().to(torch.int32).contiguous().view(1, n)
+    keep, cnt = nms_batched_raw(b, s, i, None, None, iou_threshold, mode, n)
+    return keep[0, : int(cnt.item())].to(torch.int64)
+
+
+def nms(boxes, scores, iou_threshold):
+    """torchvision.ops.nms equivalent (re-exported by layers/nms.py:6)."""
+    return batched_nms(boxes, scores, torch.zeros(len(scores), dtype=torch.int32, device=boxes.device), iou_threshold)
+
+
+# ------------------------------------------------------------------------------------------------
+# ROIAlign
+# ------------------------------------------------------------------------------------------------
+def roi_align_nhwc(feats, rois, *, scales, pooled, sampling_ratio=0, aligned=True, counts=None, per_image=0,
+                   num_rois=None, out=None, want_levels=False):
+    """feats: list (1 or 4) of NHWC tensors (fp16 or fp32, same dtype/C); rois: [R,5] or boxes [N,per_image,4]."""
+    f0 = feats[0]
+    _lib.require_cuda(f0, rois)
+    N, C = f0.shape[0], f0.shape[3]
+    dtype = 0 if f0.dtype == torch.float16 else 1
+    have_b = rois.dim() == 2 and rois.shape[1] == 5
+    R = rois.shape[0] if have_b else (num_rois if num_rois is not None else rois.shape[0] * rois.shape[1])
+    if out is None:
+        out = torch.empty((R, pooled[0], pooled[1], C), dtype=f0.dtype, device=f0.device)
+    lv = torch.empty((R,), dtype=torch.int32, device=f0.device) if want_levels else None
+    nl = len(feats)
+    ptrs = (ctypes.c_void_p * nl)(*[f.data_ptr() for f in feats])
+    hw = (ctypes.c_int32 * (2 * nl))(*sum([[f.shape[1], f.shape[2]] for f in feats], []))
+    sc = (ctypes.c_float * nl)(*scales)
+    st = _lib.lib().pe_roi_align_nhwc(ptrs, hw, sc, nl, N, C, dtype, _lib.ptr(rois.contiguous()), int(have_b), R,
+                                      int(per_image), _lib.ptr(counts), pooled[0], pooled[1], int(sampling_ratio),
+                                      int(bool(aligned)), _lib.ptr(out), _lib.ptr(lv), _lib.stream())
+    _lib.check(st, "pe_roi_align_nhwc")
+    return (out, lv) if want_levels else out
+
+
+class ROIAlign:
+    """Drop-in for detectron2.layers.ROIAlign (layers/roi_align.py:51-96): NCHW input, rois [K,5],
+    returns [K,C,ph,pw] in the input dtype.  (The detector itself stays in NHWC and calls roi_align_nhwc.)"""
+
+    def __init__(self, output_size, spatial_scale, sampling_ratio, aligned=True):
+        self.output_size = (output_size, output_size) if isinstance(output_size, int) else tuple(output_size)
+        self.spatial_scale = spatial_scale
+        self.sampling_ratio = sampling_ratio
+        self.aligned = aligned
+
+    def __call__(self, input, rois):
+        assert rois.dim() == 2 and rois.size(1) == 5
+        _lib.require_cuda(input, rois)
+        C = input.shape[1]
+        x = input.detach().permute(0, 2, 3, 1).contiguous()
+        if x.dtype not in (torch.float16, torch.float32):
+            x = x.float()
+        pad = (-C) % (8 if x.dtype == torch.float16 else 4)
+        if pad:
+            x = torch.nn.functional.pad(x, (0, pad))
+        out = roi_align_nhwc([x], rois.float(), scales=[self.spatial_scale], pooled=self.output_size,
+                             sampling_ratio=self.sampling_ratio, aligned=self.aligned)
+        return out[..., :C].permute(0, 3, 1, 2).contiguous().to(input.dtype)
+
+    forward = __call__
+
+    def __repr__(self):
+        return (f"ROIAlign(output_size={self.output_size}, spatial_scale={self.spatial_scale}, "
+                f"sampling_ratio={self.sampling_ratio}, aligned={self.aligned})")
+
+
+# ------------------------------------------------------------------------------------------------
+# conv / gemm
+# ------------------------------------------------------------------------------------------------
+def conv2d_nhwc(x, weight, bias, *, kernel, stride=1, relu=False, residual=None, residual_mode=0,
+                out=None, out_f32=False, cout_store=0, out_stride=0, cout=None):
+    """x [N,H,W,Cin] fp16 NHWC; weight packed [Cout,KH,KW,Cin] fp16 ([Cout,8,8,4] for the 7x7 stem);
+    bias fp32 [Cout] or None.  Returns NHWC fp16 (or fp32 [N,Ho,Wo,out_stride] when out_f32)."""
+    _lib.require_cuda(x, weight)
+    N, H, W, Cin = x.shape
+    Cout = cout if cout is not None else weight.shape[0]
+    if kernel == 1:
+        Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    elif kernel == 3:
+        Ho, Wo = H, W
+    else:
+        Ho, Wo = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+    if out is None:
+        if out_f32:
+            out = torch.empty((N, Ho, Wo, out_stride or Cout), dtype=torch.float32, device=x.device)
+        else:
+            out = torch.empty((N, Ho, Wo, out_stride or Cout), dtype=torch.float16, device=x.device)
+    rh, rw = (residual.shape[1], residual.shape[2]) if residual is not None else (0, 0)
+    st = _lib.lib().pe_conv2d_nhwc_f16(_lib.ptr(x), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(residual), _lib.ptr(out),
+                                       N, H, W, Cin, Cout, kernel, stride, int(relu), int(residual_mode), rh, rw,
+                                       int(out_f32), int(cout_store), int(out_stride), _lib.stream())
+    _lib.check(st, "pe_conv2d_nhwc_f16")
+    return out
+
+
+def linear_f16(x, weight, bias, *, relu=False, out_f32=False, cout_store=0, out_stride=0):
+    """x [M,K] fp16, weight [Cout,K] fp16 -> [M,Cout]: the conv kernel with H = W = 1."""
+    M, K = x.shape
+    y = conv2d_nhwc(x.view(M, 1, 1, K), weight.view(weight.shape[0], 1, 1, K), bias, kernel=1, relu=relu,
+                    out_f32=out_f32, cout_store=cout_store, out_stride=out_stride)
+    return y.view(M, -1)
+
+
+def maxpool3x3s2_nhwc(x):
+    N, H, W, C = x.shape
+    out = torch.empty((N, (H - 1) // 2 + 1, (W - 1) // 2 + 1, C), dtype=torch.float16, device=x.device)
+    _lib.check(_lib.lib().pe_maxpool3x3s2_nhwc(_lib.ptr(x), _lib.ptr(out), N, H, W, C, _lib.stream()), "pe_maxpool3x3s2_nhwc")
+    return out
+
+
+def subsample2_nhwc(x):
+    N, H, W, C = x.shape
+    out = torch.empty((N, (H - 1) // 2 + 1, (W - 1) // 2 + 1, C), dtype=torch.float16, device=x.device)
+    _lib.check(_lib.lib().pe_subsample2_nhwc(_lib.ptr(x), _lib.ptr(out), N, H, W, C, _lib.stream()), "pe_subsample2_nhwc")
+    return out
+
+
+def preprocess_pack(src, dst, *, src_kind, ch0, nch, flip_rgb, dst_hw, mean, std):
+    """src: one image (HWC u8 / HWC f32 / CHW f32 device tensor); dst: [pad_h,pad_w,4] fp16 view."""
+    _lib.require_cuda(src, dst)
+    if src_kind == 2:
+        c, h, w = src.shape
+    else:
+        h, w, c = src.shape
+    m = (ctypes.c_float * 4)(*(list(mean) + [0.0] * (4 - len(mean))))
+    s = (ctypes.c_float * 4)(*(list(std) + [1.0] * (4 - len(std))))
+    st = _lib.lib().pe_preprocess_pack(_lib.ptr(src), src_kind, h, w, c, ch0, nch, int(flip_rgb), dst_hw[0], dst_hw[1],
+                                       dst.shape[0], dst.shape[1], m, s, _lib.ptr(dst), _lib.stream())
+    _lib.check(st, "pe_preprocess_pack")

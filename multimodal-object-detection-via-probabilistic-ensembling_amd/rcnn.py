@@ -1,0 +1,295 @@
+"""GeneralizedRCNN inference on MI355X: the whole Faster R-CNN R50/R101-FPN forward as a stream of
+HIP kernel launches over a batch (no host synchronisation until results are read).
+
+Mirrors the call contract of the reference's meta-architecture
+(detectron2/modeling/meta_arch/rcnn.py:146-302): `model(list[dict])` with "image" = CHW float tensor in
+cfg.INPUT.FORMAT channel order (already resized), optional "height"/"width" = output resolution, returning
+`list[{"instances": Instances}]` with pred_boxes / scores / pred_classes (+ class_logits, prob_score, vars).
+Stage by stage it replaces: preprocess_image :269-286, ResNet/FPN (backbone/resnet.py, fpn.py),
+StandardRPNHead + RPN.forward (proposal_generator/rpn.py:74-187), find_top_rpn_proposals
+(rpn_outputs.py:52-161), ROIPooler (poolers.py:180-235), FastRCNNConvFCHead + FastRCNNOutputLayers
+(roi_heads/box_head.py:73-81, fast_rcnn.py:531-545), FastRCNNOutputs.inference (fast_rcnn.py:417-452)
+and detector_postprocess (postprocessing.py:8-38).
+"""
+import ctypes
+import math
+from dataclasses import dataclass
+
+import torch
+
+from . import _lib
+from . import layers as L
+from .structures import Boxes, Instances
+from .weights import STAGE_BLOCKS, PackedDetector
+
+SCALE_CLAMP = math.log(1000.0 / 16)
+
+
+@dataclass
+class DetectorConfig:
+    """The handful of cfg keys the inference path reads."""
+    num_classes: int = 3
+    input_format: str = "BGR"          # BGR | RGB | BGRT | BGRTTT
+    pixel_mean: tuple = (103.53, 116.28, 123.675)
+    pixel_std: tuple = (1.0, 1.0, 1.0)
+    anchor_sizes: tuple = (32, 64, 128, 256, 512)
+    aspect_ratios: tuple = (0.5, 1.0, 2.0)
+    pre_nms_topk: int = 1000
+    post_nms_topk: int = 1000
+    rpn_nms_thresh: float = 0.7
+    score_thresh: float = 0.5
+    nms_thresh: float = 0.5
+    detections_per_image: int = 100
+    min_size_test: int = 800
+    max_size_test: int = 1333
+    output_logits: bool = True
+    enable_gaussian_nll: bool = True
+    fix_vars: bool = False
+    size_divisibility: int = 32
+
+    @property
+    def in_channels(self):
+        return {"BGR": 3, "RGB": 3, "BGRT": 4, "BGRTTT": 6}[self.input_format]
+
+
+def cell_anchor_table(sizes, ratios):
+    """generate_cell_anchors (modeling/anchor_generator.py:148-180): float64 closed form, stored as float32."""
+    out = []
+    for s in sizes:
+        area = float(s) ** 2.0
+        for r in ratios:
+            w = math.sqrt(area / r)
+            h = r * w
+            out += [-w / 2.0, -h / 2.0, w / 2.0, h / 2.0]
+    return out
+
+
+class GeneralizedRCNN:
+    def __init__(self, cfg: DetectorConfig, state_dict, device="cuda"):
+        if not torch.cuda.is_available():
+            raise _lib.HipLibraryError("GeneralizedRCNN (MODEL.DEVICE=cuda) needs an MI355X; there is no CPU fallback "
+                                       "in proben_amd (the CPU restatement lives in oracle/ for testing only).")
+        _lib.lib()
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self.w = PackedDetector(state_dict, device, cfg.num_classes)
+        self.depth = self.w.depth
+        assert len(cfg.aspect_ratios) == 3, "kernels assume 3 anchors per cell"
+        self._cells = (ctypes.c_float * (len(cfg.anchor_sizes) * 12))(*cell_anchor_table(cfg.anchor_sizes, cfg.aspect_ratios))
+        self._reg_w = (ctypes.c_float * 4)(10.0, 10.0, 5.0, 5.0)
+        self.training = False
+
+    def eval(self):
+        return self
+
+    # ------------------------------------------------------------------ stages
+    def _conv(self, x, name, **kw):
+        w, b = self.w.convs[name]
+        return L.conv2d_nhwc(x, w, b, **kw)
+
+    def _bottom_up(self, x, prefix):
+        bu = prefix + ".bottom_up"
+        x = self._conv(x, bu + ".stem.conv1", kernel=7, stride=2, relu=True)
+        x = L.maxpool3x3s2_nhwc(x)
+        outs = []
+        for si, nb in enumerate(STAGE_BLOCKS[self.depth]):
+            for bi in range(nb):
+                p = f"{bu}.res{si + 2}.{bi}"
+                stride = 2 if (bi == 0 and si > 0) else 1
+                sc = self._conv(x, p + ".shortcut", kernel=1, stride=stride) if (p + ".shortcut") in self.w.convs else x
+                o = self._conv(x, p + ".conv1", kernel=1, stride=stride, relu=True)
+                o = self._conv(o, p + ".conv2", kernel=3, relu=True)
+                x = self._conv(o, p + ".conv3", kernel=1, relu=True, residual=sc, residual_mode=1)
+            outs.append(x)
+        return outs  # res2..res5
+
+    def _fpn(self, x, prefix="backbone", outs=None, ch_off=0, ch_total=256):
+        """Returns [p2,p3,p4,p5,p6].  With `outs` given (middle fusion) the 3x3 output convs write their
+        256 channels at channel offset ch_off of the preallocated [N,H,W,ch_total] tensors."""
+        res = self._bottom_up(x, prefix)
+        feats = [None] * 5
+        prev = None
+        for i in (5, 4, 3, 2):
+            c = res[i - 2]
+            if prev is None:
+                prev = self._conv(c, f"{prefix}.fpn_lateral{i}", kernel=1)
+            else:
+                prev = self._conv(c, f"{prefix}.fpn_lateral{i}", kernel=1, residual=prev, residual_mode=2)
+            if outs is None:
+                feats[i - 2] = self._conv(prev, f"{prefix}.fpn_output{i}", kernel=3)
+            else:
+                view = outs[i - 2].view(-1)[ch_off:]
+                self._conv(prev, f"{prefix}.fpn_output{i}", kernel=3, out=view, out_stride=ch_total)
+                feats[i - 2] = outs[i - 2]
+        if outs is None:
+            feats[4] = L.subsample2_nhwc(feats[3])
+        return feats
+
+    def _preprocess(self, images, resize_to=None):
+        """images: list of device tensors.  CHW float32 (reference contract, already resized) or HWC uint8 /
+        float32 raw frames (then `resize_to` = (h, w) applies ResizeShortestEdge's target on the GPU).
+        Returns NHWC4 fp16 batch(es) and [(h, w)] of the resized, unpadded images."""
+        cfg = self.cfg
+        C = cfg.in_channels
+        sizes, kinds = [], []
+        for im in images:
+            chw = im.dim() == 3 and im.shape[0] == C and im.dtype == torch.float32 and im.shape[2] != C
+            kinds.append(2 if chw else (0 if im.dtype == torch.uint8 else 1))
+            h, w = (im.shape[1], im.shape[2]) if chw else (im.shape[0], im.shape[1])
+            sizes.append(tuple(resize_to) if (resize_to is not None and not chw) else (h, w))
+        d = cfg.size_divisibility
+        Hp = (max(s[0] for s in sizes) + d - 1) // d * d
+        Wp = (max(s[1] for s in sizes) + d - 1) // d * d
+        mean = list(cfg.pixel_mean)
+        std = list(cfg.pixel_std) + [cfg.pixel_std[-1]] * (C - len(cfg.pixel_std))
+        assert len(mean) == C, f"PIXEL_MEAN needs {C} entries for INPUT.FORMAT {cfg.input_format}"
+        N = len(images)
+        groups = [(0, min(C, 4))] if C <= 4 else [(0, 3), (3, 3)]
+        batches = []
+        for ch0, nch in groups:
+            x = torch.empty((N, Hp, Wp, 4), dtype=torch.float16, device=self.device)
+            for i, im in enumerate(images):
+                L.preprocess_pack(im.contiguous(), x[i], src_kind=kinds[i], ch0=ch0, nch=nch, flip_rgb=False,
+                                  dst_hw=sizes[i], mean=mean[ch0:ch0 + nch], std=std[ch0:ch0 + nch])
+            batches.append(x)
+        return batches, sizes
+
+    def _rpn(self, feats, sizes_dev, N):
+        cfg = self.cfg
+        heads, hw, strides = [], [], [4, 8, 16, 32, 64]
+        for f in feats:
+            t = self._conv(f, "rpn.conv", kernel=3, relu=True)
+            w, b = self.w.convs["rpn.head"]
+            heads.append(L.conv2d_nhwc(t, w, b, kernel=1, out_f32=True, cout=15, cout_store=15, out_stride=16))
+            hw += [f.shape[1], f.shape[2]]
+        nl = len(feats)
+        topk = [min(cfg.pre_nms_topk, f.shape[1] * f.shape[2] * 3) for f in feats]
+        ncand = sum(topk)
+        dev = self.device
+        cb = torch.empty((N, ncand, 4), dtype=torch.float32, device=dev)
+        cs = torch.empty((N, ncand), dtype=torch.float32, device=dev)
+        cl = torch.empty((N, ncand), dtype=torch.int32, device=dev)
+        cv = torch.empty((N, ncand), dtype=torch.uint8, device=dev)
+        ptrs = (ctypes.c_void_p * nl)(*[h.data_ptr() for h in heads])
+        st = _lib.lib().pe_rpn_select_topk(ptrs, (ctypes.c_int32 * (2 * nl))(*hw), (ctypes.c_int32 * nl)(*strides[:nl]),
+                                          self._cells, nl, N, 16, cfg.pre_nms_topk, _lib.ptr(sizes_dev), SCALE_CLAMP,
+                                          _lib.ptr(cb), _lib.ptr(cs), _lib.ptr(cl), _lib.ptr(cv), ncand, _lib.stream())
+        _lib.check(st, "pe_rpn_select_topk")
+        mode = 1 if ncand * 4 > 20000 else 0  # torchvision.batched_nms dispatch (GPU threshold)
+        keep, kcnt = L.nms_batched_raw(cb, cs, cl, None, cv, cfg.rpn_nms_thresh, mode, cfg.post_nms_topk)
+        props = torch.empty((N, cfg.post_nms_topk, 4), dtype=torch.float32, device=dev)
+        plog = torch.empty((N, cfg.post_nms_topk), dtype=torch.float32, device=dev)
+        st = _lib.lib().pe_gather_boxes(_lib.ptr(cb), _lib.ptr(cs), _lib.ptr(keep), _lib.ptr(kcnt), N, ncand,
+                                       cfg.post_nms_topk, _lib.ptr(props), _lib.ptr(plog), _lib.stream())
+        _lib.check(st, "pe_gather_boxes")
+        return props, plog, kcnt, heads
+
+    def _roi_heads(self, feats, props, pcnt, sizes_dev, out_dev, N):
+        cfg, w = self.cfg, self.w
+        P = cfg.post_nms_topk
+        K = cfg.num_classes
+        dev = self.device
+        C = feats[0].shape[3]
+        pooled = L.roi_align_nhwc(feats[:4], props, scales=[1 / 4, 1 / 8, 1 / 16, 1 / 32], pooled=(7, 7),
+                                  sampling_ratio=0, aligned=True, counts=pcnt, per_image=P, num_rois=N * P)
+        x = L.linear_f16(pooled.view(N * P, 49 * C), w.fc1[0], w.fc1[1], relu=True)
+        x = L.linear_f16(x, w.fc2[0], w.fc2[1], relu=True)
+        head = L.linear_f16(x, w.predictor[0], w.predictor[1], out_f32=True, cout_store=w.head_cols, out_stride=w.head_stride)
+        cmax = min(P * K, 16384)
+        cb = torch.empty((N, cmax, 4), dtype=torch.float32, device=dev)
+        cs = torch.empty((N, cmax), dtype=torch.float32, device=dev)
+        cc = torch.empty((N, cmax), dtype=torch.int32, device=dev)
+        cr = torch.empty((N, cmax, 2), dtype=torch.int32, device=dev)
+        ccnt = torch.empty((N,), dtype=torch.int32, device=dev)
+        probs = torch.empty((N, P, K + 1), dtype=torch.float32, device=dev)
+        lib = _lib.lib()
+        st = lib.pe_boxhead_candidates(_lib.ptr(head), w.head_stride, N, P, K, _lib.ptr(pcnt), _lib.ptr(props),
+                                       _lib.ptr(sizes_dev), self._reg_w, SCALE_CLAMP, cfg.score_thresh, cmax,
+                                       _lib.ptr(cb), _lib.ptr(cs), _lib.ptr(cc), _lib.ptr(cr), _lib.ptr(ccnt),
+                                       _lib.ptr(probs), _lib.stream())
+        _lib.check(st, "pe_boxhead_candidates")
+        D = cfg.detections_per_image
+        mode = 1 if cmax * 4 > 20000 else 0
+        keep, kcnt = L.nms_batched_raw(cb, cs, cc, ccnt, None, cfg.nms_thresh, mode, D)
+        det = {
+            "boxes": torch.empty((N, D, 4), dtype=torch.float32, device=dev),
+            "scores": torch.empty((N, D), dtype=torch.float32, device=dev),
+            "classes": torch.empty((N, D), dtype=torch.int32, device=dev),
+            "class_logits": torch.empty((N, D, K + 1), dtype=torch.float32, device=dev),
+            "prob_score": torch.empty((N, D, K), dtype=torch.float32, device=dev),
+            "vars": torch.empty((N, D), dtype=torch.float32, device=dev),
+            "rows": torch.empty((N, D), dtype=torch.int32, device=dev),
+            "counts": torch.empty((N,), dtype=torch.int32, device=dev),
+        }
+        st = lib.pe_boxhead_finalize(_lib.ptr(head), w.head_stride, N, P, K, cmax, D, int(cfg.fix_vars), _lib.ptr(probs),
+                                     _lib.ptr(cb), _lib.ptr(cs), _lib.ptr(cc), _lib.ptr(cr), _lib.ptr(keep), _lib.ptr(kcnt),
+                                     _lib.ptr(sizes_dev), _lib.ptr(out_dev), _lib.ptr(det["boxes"]), _lib.ptr(det["scores"]),
+                                     _lib.ptr(det["classes"]), _lib.ptr(det["class_logits"]), _lib.ptr(det["prob_score"]),
+                                     _lib.ptr(det["vars"]), _lib.ptr(det["rows"]), _lib.ptr(det["counts"]), _lib.stream())
+        _lib.check(st, "pe_boxhead_finalize")
+        det["_head"] = head
+        det["_pooled"] = pooled
+        return det
+
+    # ------------------------------------------------------------------ public API
+    @torch.no_grad()
+    def forward_batch(self, images, out_sizes=None, resize_to=None, keep_intermediates=False):
+        """Batched device-resident forward.  images: list of device tensors (see _preprocess).
+        out_sizes: list of (height, width) per image for the final rescale (default: resized size).
+        Returns a dict of padded device tensors: boxes [N,D,4], scores, classes, class_logits,
+        prob_score, vars, counts [N]."""
+        N = len(images)
+        batches, sizes = self._preprocess(images, resize_to)
+        dev = self.device
+        sizes_dev = torch.tensor(sizes, dtype=torch.int32, device=dev)
+        out_sizes = out_sizes if out_sizes is not None else sizes
+        out_dev = torch.tensor([tuple(s) for s in out_sizes], dtype=torch.int32, device=dev)
+        if self.w.middle_fusion:
+            Hp, Wp = batches[0].shape[1], batches[0].shape[2]
+            shapes = [(Hp // s, Wp // s) for s in (4, 8, 16, 32)]
+            outs = [torch.empty((N, h, w, 512), dtype=torch.float16, device=dev) for h, w in shapes]
+            # Q1: the reference's INFERENCE runs both halves through `backbone` (meta_arch/rcnn.py:243-244)
+            self._fpn(batches[0], "backbone", outs, 0, 512)
+            self._fpn(batches[1], "backbone", outs, 256, 512)
+            feats = outs + [L.subsample2_nhwc(outs[3])]
+        else:
+            feats = self._fpn(batches[0], "backbone")
+        props, plog, pcnt, heads = self._rpn(feats, sizes_dev, N)
+        det = self._roi_heads(feats, props, pcnt, sizes_dev, out_dev, N)
+        det["proposals"], det["proposal_logits"], det["proposal_counts"] = props, plog, pcnt
+        det["image_sizes"], det["out_sizes"] = sizes, [tuple(s) for s in out_sizes]
+        if keep_intermediates:
+            det["_feats"], det["_rpn_heads"], det["_input"] = feats, heads, batches
+        else:
+            det.pop("_head", None)
+            det.pop("_pooled", None)
+        return det
+
+    def to_instances(self, det):
+        """Device result dict -> list[{"instances": Instances}] (one host sync)."""
+        counts = det["counts"].cpu().tolist()
+        cfg = self.cfg
+        out = []
+        for n, c in enumerate(counts):
+            inst = Instances(tuple(det["out_sizes"][n]))
+            inst.pred_boxes = Boxes(det["boxes"][n, :c])
+            inst.scores = det["scores"][n, :c]
+            inst.pred_classes = det["classes"][n, :c].to(torch.int64)
+            if cfg.output_logits:
+                inst.class_logits = det["class_logits"][n, :c]
+                inst.prob_score = det["prob_score"][n, :c]
+            if cfg.enable_gaussian_nll:
+                inst.vars = det["vars"][n, :c].unsqueeze(1)
+            out.append({"instances": inst})
+        return out
+
+    def inference(self, batched_inputs, do_postprocess=True):
+        assert not self.training
+        images = [x["image"].to(self.device) for x in batched_inputs]
+        out_sizes = [(x.get("height", x["image"].shape[-2]), x.get("width", x["image"].shape[-1])) for x in batched_inputs]
+        if not do_postprocess:
+            out_sizes = None
+        return self.to_instances(self.forward_batch(images, out_sizes))
+
+    def __call__(self, batched_inputs):
+        return self.inference(batched_inputs)

@@ -1,0 +1,118 @@
+"""Turn a reference-format state dict (SURVEY A.3 key names; what `torch.save(model.state_dict())`
+of the reference's GeneralizedRCNN holds, demo/FLIR/demo_train_FLIR.py:113) into the packed device
+tensors the HIP kernels consume:
+
+  * FrozenBatchNorm2d folded into the preceding conv: scale = gamma * rsqrt(var + 1e-5),
+    shift = beta - mean * scale (layers/batch_norm.py:45-65) -> fp16 weight * scale, fp32 bias = shift;
+  * conv weights [Cout,Cin,KH,KW] -> [Cout,KH,KW,Cin] fp16 (K contiguous for the MFMA B operand);
+  * 7x7 stem -> [64, 8, 8, 4] (zero row / column / channel padding, see csrc/conv_igemm.hip);
+  * RPN objectness (3) + anchor_deltas (12) fused into one [15, C] head;
+  * fc1 columns permuted from (c, ph, pw) to the ROIAlign kernel's (ph, pw, c) order;
+  * cls_score (K+1) + bbox_pred (4K) + var_pred (1) fused into one [5K+2, 1024] predictor.
+"""
+import torch
+
+BN_EPS = 1e-5
+STAGE_BLOCKS = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3)}
+
+
+def load_state_dict_file(path):
+    """`.pth` written by torch.save: a raw state dict or {"model": state_dict} (checkpoint/detection_checkpoint.py)."""
+    obj = torch.load(path, map_location="cpu")
+    if isinstance(obj, dict) and "model" in obj and isinstance(obj["model"], dict):
+        obj = obj["model"]
+    return {k: (v if isinstance(v, torch.Tensor) else torch.as_tensor(v)) for k, v in obj.items()}
+
+
+def infer_depth(sd, prefix="backbone.bottom_up"):
+    n = len({k.split(".")[3] for k in sd if k.startswith(prefix + ".res4.")})
+    for d, blocks in STAGE_BLOCKS.items():
+        if blocks[2] == n:
+            return d
+    raise ValueError(f"unsupported ResNet depth: res4 has {n} blocks")
+
+
+def _fold(sd, name):
+    w = sd[name + ".weight"].float()
+    scale = sd[name + ".norm.weight"].float() * torch.rsqrt(sd[name + ".norm.running_var"].float() + BN_EPS)
+    shift = sd[name + ".norm.bias"].float() - sd[name + ".norm.running_mean"].float() * scale
+    return w * scale.view(-1, 1, 1, 1), shift
+
+
+def _pack_conv(w):
+    return w.permute(0, 2, 3, 1).contiguous().half()
+
+
+def _pack_stem(w):
+    cout, cin = w.shape[0], w.shape[1]
+    p = torch.zeros((cout, 8, 8, 4), dtype=torch.float32)
+    p[:, :7, :7, :cin] = w.permute(0, 2, 3, 1)
+    return p.half()
+
+
+class PackedDetector:
+    """Device-resident packed weights of one detector."""
+
+    def __init__(self, sd, device="cuda", num_classes=None):
+        self.device = torch.device(device)
+        self.depth = infer_depth(sd)
+        self.has_backbone_2 = any(k.startswith("backbone_2.") for k in sd)
+        self.stem_in = sd["backbone.bottom_up.stem.conv1.weight"].shape[1]
+        self.rpn_channels = sd["proposal_generator.rpn_head.conv.weight"].shape[0]
+        self.middle_fusion = self.rpn_channels == 512
+        ncls = sd["roi_heads.box_predictor.cls_score.weight"].shape[0] - 1
+        self.num_classes = num_classes if num_classes is not None else ncls
+        assert self.num_classes == ncls, (self.num_classes, ncls)
+        self.convs = {}
+        self._pack_backbone(sd, "backbone")
+        if self.has_backbone_2:
+            self._pack_backbone(sd, "backbone_2")
+        dev = self.device
+        p = "proposal_generator.rpn_head"
+        self.convs["rpn.conv"] = (_pack_conv(sd[p + ".conv.weight"].float()).to(dev), sd[p + ".conv.bias"].float().to(dev))
+        hw = torch.cat([sd[p + ".objectness_logits.weight"].float(), sd[p + ".anchor_deltas.weight"].float()], 0)
+        hb = torch.cat([sd[p + ".objectness_logits.bias"].float(), sd[p + ".anchor_deltas.bias"].float()], 0)
+        assert hw.shape[0] == 15, "expected 3 anchors per cell"
+        self.convs["rpn.head"] = (_pack_conv(hw).to(dev), hb.to(dev))
+        C = self.rpn_channels
+        w1 = sd["roi_heads.box_head.fc1.weight"].float()
+        w1 = w1.view(w1.shape[0], C, 7, 7).permute(0, 2, 3, 1).reshape(w1.shape[0], 49 * C)
+        self.fc1 = (w1.contiguous().half().to(dev), sd["roi_heads.box_head.fc1.bias"].float().to(dev))
+        self.fc2 = (sd["roi_heads.box_head.fc2.weight"].half().contiguous().to(dev), sd["roi_heads.box_head.fc2.bias"].float().to(dev))
+        q = "roi_heads.box_predictor"
+        has_var = (q + ".var_pred.weight") in sd
+        pw = [sd[q + ".cls_score.weight"].float(), sd[q + ".bbox_pred.weight"].float()]
+        pb = [sd[q + ".cls_score.bias"].float(), sd[q + ".bbox_pred.bias"].float()]
+        if has_var:
+            pw.append(sd[q + ".var_pred.weight"].float())
+            pb.append(sd[q + ".var_pred.bias"].float())
+        else:  # ENABLE_GAUSSIANNLLOSS off: log-variance 0 -> variance 1
+            pw.append(torch.zeros(1, pw[0].shape[1]))
+            pb.append(torch.zeros(1))
+        self.has_var = has_var
+        self.predictor = (torch.cat(pw, 0).half().contiguous().to(dev), torch.cat(pb, 0).to(dev))
+        self.head_cols = 5 * self.num_classes + 2
+        self.head_stride = (self.head_cols + 7) // 8 * 8
+
+    def _pack_backbone(self, sd, prefix):
+        dev = self.device
+        bu = prefix + ".bottom_up"
+        w, b = _fold(sd, bu + ".stem.conv1")
+        self.convs[bu + ".stem.conv1"] = (_pack_stem(w).to(dev), b.to(dev))
+        for si, nb in enumerate(STAGE_BLOCKS[self.depth]):
+            for bi in range(nb):
+                for c in ("conv1", "conv2", "conv3", "shortcut"):
+                    name = f"{bu}.res{si + 2}.{bi}.{c}"
+                    if name + ".weight" in sd:
+                        w, b = _fold(sd, name)
+                        self.convs[name] = (_pack_conv(w).to(dev), b.to(dev))
+        for i in (2, 3, 4, 5):
+            for kind in ("fpn_lateral", "fpn_output"):
+                name = f"{prefix}.{kind}{i}"
+                self.convs[name] = (_pack_conv(sd[name + ".weight"].float()).to(dev), sd[name + ".bias"].float().to(dev))
+
+    def nbytes(self):
+        tot = sum(w.numel() * w.element_size() + b.numel() * 4 for w, b in self.convs.values())
+        for w, b in (self.fc1, self.fc2, self.predictor):
+            tot += w.numel() * 2 + b.numel() * 4
+        return tot

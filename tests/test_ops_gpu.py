@@ -1,0 +1,322 @@
+"""Op-level parity of the HIP kernels (through the C-ABI) against a plain torch fp32 reference (conv / pool /
+pack) and against the oracle (NMS, RPN selection, ROIAlign, box-head post-processing)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def L():
+    import proben_amd  # noqa: F401
+    from proben_amd import layers
+    return layers
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+# ------------------------------------------------------------------------------------------------ conv
+CONV_CASES = [
+    # (N, H, W, Cin, Cout, kernel, stride, relu, res_mode, f32out)
+    (2, 25, 32, 256, 256, 3, 1, True, 0, False),
+    (1, 50, 64, 64, 64, 3, 1, True, 0, False),
+    (2, 13, 16, 512, 128, 3, 1, False, 0, False),
+    (2, 50, 64, 256, 1024, 1, 1, True, 1, False),
+    (2, 50, 64, 1024, 256, 1, 1, True, 0, False),
+    (3, 51, 63, 256, 512, 1, 2, False, 0, False),
+    (2, 26, 32, 512, 256, 1, 1, False, 2, False),
+    (2, 20, 24, 256, 15, 1, 1, False, 0, True),
+    (1, 37, 41, 64, 256, 1, 1, False, 0, False),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_matches_torch(L, case):
+    N, H, W, Cin, Cout, k, s, relu, res_mode, f32out = case
+    g = torch.Generator(device="cpu").manual_seed(hash(case) % 2**31)
+    x = torch.randn(N, Cin, H, W, generator=g).cuda().half()
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).cuda().half()
+    b = torch.randn(Cout, generator=g).cuda()
+    ref = torch.nn.functional.conv2d(x.float(), w.float(), b, stride=s, padding=k // 2)
+    res = None
+    if res_mode == 1:
+        res = torch.randn(ref.shape, generator=g).cuda().half()
+        ref = ref + res.float()
+        res = nhwc(res)
+    elif res_mode == 2:
+        res = torch.randn(N, Cout, (ref.shape[2] + 1) // 2, (ref.shape[3] + 1) // 2, generator=g).cuda().half()
+        ref = ref + torch.nn.functional.interpolate(res.float(), scale_factor=2, mode="nearest")[:, :, : ref.shape[2], : ref.shape[3]]
+        res = nhwc(res)
+    if relu:
+        ref = ref.relu()
+    wp = w.permute(0, 2, 3, 1).contiguous()
+    if f32out:
+        out = L.conv2d_nhwc(nhwc(x), wp, b, kernel=k, stride=s, relu=relu, out_f32=True, cout=Cout, cout_store=Cout, out_stride=16)
+        got = out[..., :Cout].permute(0, 3, 1, 2)
+        tol = dict(rtol=1e-3, atol=1e-3)
+    else:
+        out = L.conv2d_nhwc(nhwc(x), wp, b, kernel=k, stride=s, relu=relu, residual=res, residual_mode=res_mode)
+        got = out.permute(0, 3, 1, 2).float()
+        tol = dict(rtol=4e-3, atol=4e-3)
+    assert got.shape == ref.shape
+    torch.testing.assert_close(got, ref, **tol)
+
+
+def test_conv_transpose_detecting(L):
+    """A = identity-like pixels, ASYMMETRIC weights: catches a row/col swap in the MFMA C layout."""
+    Cin = Cout = 128
+    x = torch.zeros(1, Cin, 4, 32).cuda().half()
+    for i in range(128):
+        x[0, i, i // 32, i % 32] = 1.0
+    w = (torch.arange(Cout * Cin, dtype=torch.float32).reshape(Cout, Cin, 1, 1) % 97 / 97.0).cuda().half()
+    out = L.conv2d_nhwc(nhwc(x), w.permute(0, 2, 3, 1).contiguous(), None, kernel=1)
+    ref = torch.nn.functional.conv2d(x.float(), w.float())
+    torch.testing.assert_close(out.permute(0, 3, 1, 2).float(), ref, rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.parametrize("cin", [3, 4])
+def test_stem_matches_torch(L, cin):
+    import proben_amd.weights as WT
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, cin, 96, 128, generator=g)
+    w = torch.randn(64, cin, 7, 7, generator=g) / (cin * 49) ** 0.5
+    b = torch.randn(64, generator=g)
+    x4 = torch.zeros(2, 96, 128, 4)
+    x4[..., :cin] = x.permute(0, 2, 3, 1)
+    out = L.conv2d_nhwc(x4.cuda().half(), WT._pack_stem(w).cuda(), b.cuda(), kernel=7, stride=2, relu=True)
+    ref = torch.nn.functional.conv2d(x.cuda().half().float(), w.cuda().half().float(), b.cuda(), stride=2, padding=3).relu()
+    torch.testing.assert_close(out.permute(0, 3, 1, 2).float(), ref, rtol=4e-3, atol=4e-3)
+
+
+def test_linear_matches_torch(L):
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(333, 12544, generator=g).cuda().half()
+    w = (torch.randn(1024, 12544, generator=g) / 112).cuda().half()
+    b = torch.randn(1024, generator=g).cuda()
+    got = L.linear_f16(x, w, b, relu=True).float()
+    ref = torch.nn.functional.linear(x.float(), w.float(), b).relu()
+    torch.testing.assert_close(got, ref, rtol=5e-3, atol=5e-3)
+
+
+def test_pools_match_torch(L):
+    x = torch.randn(2, 64, 37, 52).cuda().half()
+    got = L.maxpool3x3s2_nhwc(nhwc(x)).permute(0, 3, 1, 2)
+    assert torch.equal(got, torch.nn.functional.max_pool2d(x.float(), 3, 2, 1).half())
+    got = L.subsample2_nhwc(nhwc(x)).permute(0, 3, 1, 2)
+    assert torch.equal(got, torch.nn.functional.max_pool2d(x, 1, 2, 0))
+
+
+def test_preprocess_pack(L):
+    img = torch.rand(3, 70, 90) * 255
+    dst = torch.empty(96, 96, 4, dtype=torch.float16).cuda()
+    mean, std = [103.53, 116.28, 123.675], [1.0, 1.0, 1.0]
+    L.preprocess_pack(img.cuda(), dst, src_kind=2, ch0=0, nch=3, flip_rgb=False, dst_hw=(70, 90), mean=mean, std=std)
+    ref = torch.zeros(96, 96, 4)
+    ref[:70, :90, :3] = (img - torch.tensor(mean).view(3, 1, 1)).permute(1, 2, 0)
+    torch.testing.assert_close(dst.cpu().float(), ref.half().float(), rtol=0, atol=0.07)
+    assert float(dst[70:].abs().max()) == 0 and float(dst[:, 90:].abs().max()) == 0
+    # fused resize path: uint8 HWC -> bilinear (half-pixel) -> rounded -> normalised
+    u8 = (torch.rand(48, 64, 3) * 255).to(torch.uint8)
+    dst = torch.empty(96, 128, 4, dtype=torch.float16).cuda()
+    L.preprocess_pack(u8.cuda(), dst, src_kind=0, ch0=0, nch=3, flip_rgb=False, dst_hw=(75, 100), mean=mean, std=std)
+    up = torch.nn.functional.interpolate(u8.permute(2, 0, 1)[None].float(), size=(75, 100), mode="bilinear", align_corners=False)[0]
+    ref = (up.round() - torch.tensor(mean).view(3, 1, 1)).permute(1, 2, 0)
+    diff = (dst[:75, :100, :3].cpu().float() - ref).abs()
+    assert float((diff > 1.01).float().mean()) < 1e-3  # rounding ties may differ by one grey level
+
+
+# ------------------------------------------------------------------------------------------------ NMS
+def rand_boxes(g, n, span=600.0, wh=120.0):
+    xy = torch.rand(n, 2, generator=g) * span
+    return torch.cat([xy, xy + torch.rand(n, 2, generator=g) * wh + 1], 1)
+
+
+@pytest.mark.parametrize("n,ncls,thr", [(1, 1, 0.5), (300, 3, 0.5), (4624, 5, 0.7), (6000, 4, 0.5)])
+def test_batched_nms_matches_oracle(L, n, ncls, thr):
+    from oracle import nms as O
+    g = torch.Generator().manual_seed(n)
+    b = rand_boxes(g, n, span=200.0 if n > 1000 else 600.0)
+    s = torch.rand(n, generator=g)
+    s[::7] = s[1::7][: len(s[::7])]  # exact ties
+    c = torch.randint(0, ncls, (n,), generator=g)
+    got = L.batched_nms(b.cuda(), s.cuda(), c.cuda(), thr).cpu().numpy()
+    want = O.batched_nms_f32(b.numpy(), s.numpy(), c.numpy(), thr, device_type="cuda")
+    np.testing.assert_array_equal(got, want)
+
+
+def test_nms_empty_and_float_class_ids(L):
+    e = L.batched_nms(torch.zeros(0, 4).cuda(), torch.zeros(0).cuda(), torch.zeros(0).cuda(), 0.5)
+    assert e.shape == (0,) and e.dtype == torch.int64
+    g = torch.Generator().manual_seed(9)
+    b, s = rand_boxes(g, 50), torch.rand(50, generator=g)
+    c = torch.randint(0, 3, (50,), generator=g).float()  # demo_probEn.py:57 passes torch.Tensor(classes)
+    from oracle import nms as O
+    got = L.batched_nms(b.cuda(), s.cuda(), c.cuda(), 0.5).cpu().numpy()
+    np.testing.assert_array_equal(got, O.batched_nms_f32(b.numpy(), s.numpy(), c.numpy(), 0.5))
+
+
+def test_nms_batched_raw_valid_mask_and_counts(L):
+    from oracle import nms as O
+    g = torch.Generator().manual_seed(21)
+    B, n = 5, 700
+    b = torch.stack([rand_boxes(g, n, span=150.0) for _ in range(B)])
+    s = torch.rand(B, n, generator=g)
+    c = torch.randint(0, 4, (B, n), generator=g).int()
+    valid = (torch.rand(B, n, generator=g) > 0.2).to(torch.uint8)
+    keep, cnt = L.nms_batched_raw(b.cuda(), s.cuda(), c.cuda(), None, valid.cuda(), 0.6, 0, 100)
+    for i in range(B):
+        sel = valid[i].bool().numpy().nonzero()[0]
+        want = sel[O.batched_nms_f32(b[i].numpy()[sel], s[i].numpy()[sel], c[i].numpy()[sel], 0.6, mode="trick")][:100]
+        np.testing.assert_array_equal(keep[i, : int(cnt[i])].cpu().numpy(), want)
+
+
+# ------------------------------------------------------------------------------------------------ RPN
+def test_rpn_select_matches_oracle():
+    import ctypes
+    import proben_amd  # noqa: F401
+    from oracle import detector as D
+    from proben_amd import _lib
+    from proben_amd.rcnn import SCALE_CLAMP, cell_anchor_table
+    spec = D.DetectorSpec()
+    g = torch.Generator().manual_seed(77)
+    N, shapes, strides = 2, [(40, 52), (20, 26), (10, 13), (5, 7), (3, 4)], [4, 8, 16, 32, 64]
+    heads, lg_l, dl_l = [], [], []
+    for (h, w) in shapes:
+        hd = torch.randn(N, h, w, 16, generator=g)
+        hd[..., 3:15] *= 0.5
+        hd[0, 0, 0, 0] = float("nan")
+        hd[1, 1, 1, 5] = float("inf")
+        hd[:, 2, :, 1] = 0.25  # exact ties
+        heads.append(hd)
+        lg_l.append(hd[..., :3].permute(0, 3, 1, 2).contiguous())                       # [N, A, H, W]
+        dl_l.append(hd[..., 3:15].permute(0, 3, 1, 2).contiguous())                     # [N, 4A, H, W]
+    sizes = [(150, 200), (160, 208)]
+    want = D.select_proposals(lg_l, dl_l, strides, sizes, spec)
+    # --- HIP: selection kernel + NMS + gather
+    from proben_amd import layers as L
+    hd_dev = [h.cuda().contiguous() for h in heads]
+    topk = [min(1000, h * w * 3) for h, w in shapes]
+    ncand = sum(topk)
+    cb = torch.empty(N, ncand, 4).cuda(); cs = torch.empty(N, ncand).cuda()
+    cl = torch.empty(N, ncand, dtype=torch.int32).cuda(); cv = torch.empty(N, ncand, dtype=torch.uint8).cuda()
+    ptrs = (ctypes.c_void_p * 5)(*[h.data_ptr() for h in hd_dev])
+    hw = (ctypes.c_int32 * 10)(*sum([list(s) for s in shapes], []))
+    cells = (ctypes.c_float * 60)(*cell_anchor_table(spec.anchor_sizes, spec.aspect_ratios))
+    sz = torch.tensor(sizes, dtype=torch.int32).cuda()
+    st = _lib.lib().pe_rpn_select_topk(ptrs, hw, (ctypes.c_int32 * 5)(*strides), cells, 5, N, 16, 1000, _lib.ptr(sz),
+                                      SCALE_CLAMP, _lib.ptr(cb), _lib.ptr(cs), _lib.ptr(cl), _lib.ptr(cv), ncand, _lib.stream())
+    _lib.check(st, "rpn")
+    keep, cnt = L.nms_batched_raw(cb, cs, cl, None, cv, 0.7, 0, 1000)
+    for n in range(N):
+        k = keep[n, : int(cnt[n])].long()
+        gb, gs = cb[n][k].cpu(), cs[n][k].cpu()
+        wb, ws = want[n]
+        assert gb.shape == wb.shape
+        np.testing.assert_array_equal(gs.numpy(), ws.numpy())
+        np.testing.assert_allclose(gb.numpy(), wb.numpy(), rtol=1e-5, atol=1e-4)  # expf: device vs libm
+
+
+# ------------------------------------------------------------------------------------------------ ROIAlign
+def test_roi_align_fp32_bit_exact_vs_oracle(L, golden_dir):
+    """The reference's own pooler fixture (4 FPN levels, level assignment, empty + full-frame boxes)."""
+    z = np.load(os.path.join(golden_dir, "detector_ops.npz"))
+    feats = [torch.from_numpy(z[f"pool_feat_l{i}"]) for i in range(4)]
+    boxes = torch.stack([torch.from_numpy(z["pool_boxes_0"]), torch.from_numpy(z["pool_boxes_1"])])  # [2,40,4]
+    out, lv = L.roi_align_nhwc([nhwc(f).cuda() for f in feats], boxes.cuda(), scales=[1 / 4, 1 / 8, 1 / 16, 1 / 32],
+                               pooled=(7, 7), counts=None, per_image=40, want_levels=True)
+    got = out.permute(0, 3, 1, 2).cpu().numpy()
+    np.testing.assert_array_equal(got, z["pool_out"])
+
+
+def test_roi_align_module_matches_reference_tables(L):
+    inp = torch.arange(25, dtype=torch.float32).reshape(1, 1, 5, 5).cuda()
+    rois = torch.tensor([[0, 1, 1, 3, 3.0]]).cuda()
+    old = [[7.5, 8, 8.5, 9], [10, 10.5, 11, 11.5], [12.5, 13, 13.5, 14], [15, 15.5, 16, 16.5]]
+    new = [[4.5, 5.0, 5.5, 6.0], [7.0, 7.5, 8.0, 8.5], [9.5, 10.0, 10.5, 11.0], [12.0, 12.5, 13.0, 13.5]]
+    np.testing.assert_allclose(L.ROIAlign((4, 4), 1.0, 0, aligned=False)(inp, rois)[0, 0].cpu(), old)
+    np.testing.assert_allclose(L.ROIAlign((4, 4), 1.0, 0, aligned=True)(inp, rois)[0, 0].cpu(), new)
+    # empty box -> zeros, empty batch -> (0, C, 7, 7)   (tests/test_roi_align.py:94-111)
+    x = torch.rand(1, 3, 9, 9).cuda()
+    assert float(L.ROIAlign(7, 1.0, 0)(x, torch.tensor([[0, 3, 3, 3, 3.0]]).cuda()).abs().max()) == 0.0
+    assert L.ROIAlign(7, 1.0, 0)(x, torch.zeros(0, 5).cuda()).shape == (0, 3, 7, 7)
+
+
+def test_roi_align_fp16_and_dead_rows(L):
+    from oracle import roi_align as RA
+    g = torch.Generator().manual_seed(4)
+    f = torch.randn(2, 256, 50, 64, generator=g).half()
+    boxes = torch.stack([rand_boxes(g, 30, span=600, wh=300) for _ in range(2)])
+    counts = torch.tensor([30, 11], dtype=torch.int32)
+    out = L.roi_align_nhwc([nhwc(f).cuda()], boxes.cuda(), scales=[1 / 16], pooled=(7, 7), counts=counts.cuda(), per_image=30)
+    rois = torch.cat([torch.cat([torch.full((30, 1), float(i)), boxes[i]], 1) for i in range(2)])
+    ref = RA.roi_align_forward(f.float(), rois, 1 / 16, 7, 7, 0, True)
+    got = out.permute(0, 3, 1, 2).float().cpu()
+    torch.testing.assert_close(got[:41], ref[:41], rtol=2e-3, atol=2e-3)
+    assert float(got[41:].abs().max()) == 0.0
+
+
+# ------------------------------------------------------------------------------------------------ box head
+def test_boxhead_matches_oracle_quirks():
+    import ctypes
+    import proben_amd  # noqa: F401
+    from oracle import detector as D
+    from proben_amd import _lib
+    from proben_amd import layers as L
+    from proben_amd.rcnn import SCALE_CLAMP
+    g = torch.Generator().manual_seed(31)
+    N, P, K = 3, 1000, 3
+    stride = 24
+    head = torch.zeros(N, P, stride)
+    head[..., : K + 1] = torch.randn(N, P, K + 1, generator=g) * 2.5
+    head[..., K + 1: 5 * K + 1] = torch.randn(N, P, 4 * K, generator=g)
+    head[..., 5 * K + 1] = torch.randn(N, P, generator=g) * 0.5
+    head[1, 17, K + 2] = float("nan")   # Q4: non-finite row dropped from boxes/scores only
+    head[2, 5, 0] = float("inf")
+    props = torch.stack([rand_boxes(g, P, span=800, wh=250) for _ in range(N)])
+    pcnt = torch.tensor([1000, 640, 1000], dtype=torch.int32)
+    sizes = [(800, 1000), (768, 960), (800, 1000)]
+    outs = [(512, 640), (492, 614), (512, 640)]
+    spec = D.DetectorSpec()
+    dev = "cuda"
+    cmax = P * K
+    hd, pr = head.view(N * P, stride).cuda(), props.cuda()
+    cb = torch.empty(N, cmax, 4, device=dev); cs = torch.empty(N, cmax, device=dev)
+    cc = torch.empty(N, cmax, dtype=torch.int32, device=dev); cr = torch.empty(N, cmax, 2, dtype=torch.int32, device=dev)
+    ccnt = torch.empty(N, dtype=torch.int32, device=dev); probs = torch.empty(N, P, K + 1, device=dev)
+    sz = torch.tensor(sizes, dtype=torch.int32, device=dev); osz = torch.tensor(outs, dtype=torch.int32, device=dev)
+    lib = _lib.lib()
+    _lib.check(lib.pe_boxhead_candidates(_lib.ptr(hd), stride, N, P, K, _lib.ptr(pcnt.cuda()), _lib.ptr(pr), _lib.ptr(sz),
+                                         (ctypes.c_float * 4)(10, 10, 5, 5), SCALE_CLAMP, 0.5, cmax, _lib.ptr(cb), _lib.ptr(cs),
+                                         _lib.ptr(cc), _lib.ptr(cr), _lib.ptr(ccnt), _lib.ptr(probs), _lib.stream()), "cand")
+    keep, kcnt = L.nms_batched_raw(cb, cs, cc, ccnt, None, 0.5, 0, 100)
+    D_ = 100
+    o = {k: torch.empty(s, dtype=t, device=dev) for k, s, t in [
+        ("boxes", (N, D_, 4), torch.float32), ("scores", (N, D_), torch.float32), ("classes", (N, D_), torch.int32),
+        ("logits", (N, D_, K + 1), torch.float32), ("probs", (N, D_, K), torch.float32), ("vars", (N, D_), torch.float32),
+        ("rows", (N, D_), torch.int32), ("counts", (N,), torch.int32)]}
+    _lib.check(lib.pe_boxhead_finalize(_lib.ptr(hd), stride, N, P, K, cmax, D_, 0, _lib.ptr(probs), _lib.ptr(cb), _lib.ptr(cs),
+                                       _lib.ptr(cc), _lib.ptr(cr), _lib.ptr(keep), _lib.ptr(kcnt), _lib.ptr(sz), _lib.ptr(osz),
+                                       _lib.ptr(o["boxes"]), _lib.ptr(o["scores"]), _lib.ptr(o["classes"]), _lib.ptr(o["logits"]),
+                                       _lib.ptr(o["probs"]), _lib.ptr(o["vars"]), _lib.ptr(o["rows"]), _lib.ptr(o["counts"]),
+                                       _lib.stream()), "final")
+    for n in range(N):
+        r = int(pcnt[n])
+        h = head[n, :r]
+        det = D.select_detections(h[:, : K + 1], h[:, K + 1: 5 * K + 1], torch.exp(h[:, 5 * K + 1: 5 * K + 2]),
+                                  props[n, :r], sizes[n], spec)
+        want = D.postprocess(det, sizes[n], outs[n])
+        c = int(o["counts"][n])
+        assert c == len(want["boxes"]), (n, c, len(want["boxes"]))
+        np.testing.assert_array_equal(o["classes"][n, :c].cpu().numpy(), want["classes"].numpy())
+        if n == 0:  # with dropped (non-finite) rows the oracle reports post-filter row ids, the kernel original ones
+            np.testing.assert_array_equal(o["rows"][n, :c].cpu().numpy(), want["roi_index"].numpy())
+        np.testing.assert_allclose(o["scores"][n, :c].cpu().numpy(), want["scores"].numpy(), rtol=2e-6, atol=1e-7)
+        np.testing.assert_allclose(o["boxes"][n, :c].cpu().numpy(), want["boxes"].numpy(), rtol=1e-5, atol=2e-4)
+        np.testing.assert_array_equal(o["logits"][n, :c].cpu().numpy(), want["class_logits"].numpy())
+        np.testing.assert_allclose(o["probs"][n, :c].cpu().numpy(), want["prob_score"].numpy(), rtol=2e-6, atol=1e-7)
+        np.testing.assert_allclose(o["vars"][n, :c].cpu().numpy(), want["vars"].numpy().reshape(-1), rtol=2e-6)
