@@ -60,7 +60,10 @@ int pe_proben_fuse_batch(const double* boxes,     /* [Ntot,4] xyxy */
                          const double* probs,     /* [Ntot,K] */
                          const double* variances, /* [Ntot] */
                          const int32_t* classes,  /* [Ntot] */
-                         const int32_t* offsets,  /* [B+1] */
+                         const int32_t* offsets,  /* [B+1] (or [B] when row_counts is given) */
+                         const int32_t* row_counts, /* optional [B]: rows of image b = row_counts[b] */
+                         const int32_t* passthrough, /* optional [B]: != 0 -> copy the rows unchanged (only ONE
+                                                        detector fired: demo_probEn.py:240-253) */
                          int32_t num_images, int32_t num_classes, int32_t max_rows_per_image,
                          int32_t score_mode, int32_t box_mode, double iou_thresh,
                          double frame_w, double frame_h, /* class-band shift: 640, 512 */
@@ -70,6 +73,22 @@ int pe_proben_fuse_batch(const double* boxes,     /* [Ntot,4] xyxy */
                          int32_t* out_keep,              /* [Ntot] row index (image-local) of each pivot */
                          int32_t* out_counts,            /* [B] */
                          void* stream);
+
+/* Detector outputs -> ProbEn input rows, on the device (replaces the JSON hop between
+ * demo/FLIR/demo_FLIR_save_predictions.py:133-176 and demo_probEn.py:205-234 + prepare_data :79-90).
+ * det_*[d]: DEVICE pointers of detector d's padded outputs: boxes f32 [B,D,4], scores f32 [B,D],
+ * classes i32 [B,D], probs f32 [B,D,K], vars f32 [B,D], counts i32 [B]  (host arrays of pointers).
+ * Rows with class > max_class are dropped (the reference keeps `classes <= 2`, :148-155).
+ * Image b's rows are written at b*row_stride in detector order; out_counts[b] = rows written;
+ * out_single_source[b] = 1 when exactly one detector contributed rows (-> passthrough). */
+int pe_proben_pack_detections(const float* const* det_boxes_host, const float* const* det_scores_host,
+                              const int32_t* const* det_classes_host, const float* const* det_probs_host,
+                              const float* const* det_vars_host, const int32_t* const* det_counts_host,
+                              int32_t num_detectors, int32_t num_images, int32_t det_stride,
+                              int32_t num_classes, int32_t max_class, int32_t row_stride, double* out_boxes,
+                              double* out_scores, double* out_probs, double* out_vars, int32_t* out_classes,
+                              int32_t* out_offsets, int32_t* out_counts, int32_t* out_single_source,
+                              void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused convolution / GEMM: NHWC fp16 activations, [Cout][KH][KW][Cin] fp16 weights, fp32 accumulate

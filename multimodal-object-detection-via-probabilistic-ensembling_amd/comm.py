@@ -1,0 +1,92 @@
+"""Rank helpers and the ONE collective of the inference path.
+
+Mirrors detectron2/utils/comm.py (get_world_size :20-25, get_rank :28-33, is_main_process :51-52,
+synchronize :55-67, all_gather :139-174, gather :177-217).  The reference pickles Python lists and moves
+them as padded uint8 tensors over a gloo (CPU/TCP) group; here the evaluation rows stay tensors:
+    counts  int32 [W]            one all_gather
+    rows    float32 [max_n, 7]   one all_gather   (image_id, x, y, w, h, score, category_id)
+over RCCL/xGMI for CUDA tensors (backend "nccl") or gloo for CPU tensors (tests), concatenated in RANK
+ORDER so the row order equals the single-GPU order (InferenceSampler shards are contiguous).
+The payload is tiny (<= 3 MB per 1000 images): one latency-bound call, no bucketing.
+"""
+import pickle
+
+import torch
+import torch.distributed as dist
+
+
+def get_world_size():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def get_rank():
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def is_main_process():
+    return get_rank() == 0
+
+
+def synchronize():
+    if get_world_size() > 1:
+        dist.barrier()
+
+
+def shard_range(num_items, rank=None, world=None):
+    """InferenceSampler (data/samplers/distributed_sampler.py:172-199): contiguous blocks of ceil(N/W)."""
+    rank = get_rank() if rank is None else rank
+    world = get_world_size() if world is None else world
+    shard = (num_items - 1) // world + 1 if num_items > 0 else 0
+    begin = shard * rank
+    return range(min(begin, num_items), min(shard * (rank + 1), num_items))
+
+
+def all_gather_rows(rows, group=None):
+    """rows: [n, C] tensor (any n per rank).  Returns [sum n, C] on every rank, rank order preserved."""
+    world = get_world_size()
+    if world == 1:
+        return rows
+    n = torch.tensor([rows.shape[0]], dtype=torch.int32, device=rows.device)
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n, group=group)
+    counts = [int(c.item()) for c in counts]
+    m = max(max(counts), 1)
+    pad = torch.zeros((m, rows.shape[1]), dtype=rows.dtype, device=rows.device)
+    pad[: rows.shape[0]] = rows
+    bufs = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(bufs, pad, group=group)
+    return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)
+
+
+def all_gather_padded(t, group=None):
+    """Fixed-shape tensor per rank -> [W, ...] (no host sync: used inside the timed bench step)."""
+    world = get_world_size()
+    if world == 1:
+        return t.unsqueeze(0)
+    out = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(out.view(-1), t.contiguous().view(-1), group=group)
+    return out
+
+
+def all_gather_fused_rows(fused):
+    """Gather one batch's fused detections (padded layout, no host sync)."""
+    return {k: all_gather_padded(fused[k]) for k in ("boxes", "scores", "classes", "counts")}
+
+
+def gather(data, dst=0, group=None):
+    """API-compatible object gather (utils/comm.py:177-217) for small Python objects (metrics dicts)."""
+    world = get_world_size()
+    if world == 1:
+        return [data]
+    out = [None] * world if get_rank() == dst else None
+    dist.gather_object(data, out, dst=dst, group=group)
+    return out if get_rank() == dst else []
+
+
+def all_gather(data, group=None):
+    world = get_world_size()
+    if world == 1:
+        return [data]
+    out = [None] * world
+    dist.all_gather_object(out, data, group=group)
+    return out

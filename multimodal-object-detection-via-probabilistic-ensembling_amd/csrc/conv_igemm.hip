@@ -184,6 +184,31 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     }
 
     // ---- epilogue: accumulators -> LDS (fp32) -> vectorised bias / residual / ReLU / store ----
+    // Each thread owns NV fixed (row, 8-channel) vectors; their residual operands are fetched FIRST so the
+    // HBM latency overlaps the accumulator -> LDS transposition instead of serialising per vector.
+    constexpr int VEC_PER_ROW = BN / 8;
+    constexpr int NV = BM * VEC_PER_ROW / 256;
+    half8 rres[NV];
+    if (a.res_mode) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int v = tid + i * 256;
+            const int r = v / VEC_PER_ROW, c8 = (v - r * VEC_PER_ROW) * 8;
+            const int m = m0 + r, c = n0 + c8;
+            rres[i] = zero8;
+            if (m < a.M && c < a.cout_store) {
+                size_t ro;
+                if (a.res_mode == 1) {
+                    ro = (size_t)m * a.Cout + c;
+                } else {
+                    const int ow = m % a.Wo, t = m / a.Wo;
+                    const int oh = t % a.Ho, n = t / a.Ho;
+                    ro = (((size_t)n * a.resH + (oh >> 1)) * a.resW + (ow >> 1)) * a.Cout + c;
+                }
+                rres[i] = *reinterpret_cast<const half8*>(a.res + ro);
+            }
+        }
+    }
     float* ep = reinterpret_cast<float*>(smem);
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -196,8 +221,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
                 ep[r * EP_ROW + c] = acc[i][j][e];
             }
     __syncthreads();
-    constexpr int VEC_PER_ROW = BN / 8;
-    for (int v = tid; v < BM * VEC_PER_ROW; v += 256) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int v = tid + i * 256;
         const int r = v / VEC_PER_ROW, c8 = (v - r * VEC_PER_ROW) * 8;
         const int m = m0 + r, c = n0 + c8;
         if (m >= a.M || c >= a.cout_store) continue;
@@ -205,21 +231,19 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         const float4v x1 = *reinterpret_cast<const float4v*>(ep + r * EP_ROW + c8 + 4);
         float x[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
         if (a.bias) {
+            if (c + 8 <= a.Cout) {
+                const float4v b0 = *reinterpret_cast<const float4v*>(a.bias + c);
+                const float4v b1 = *reinterpret_cast<const float4v*>(a.bias + c + 4);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) x[e] += (c + e < a.Cout) ? a.bias[c + e] : 0.f;
+                for (int e = 0; e < 4; ++e) { x[e] += b0[e]; x[e + 4] += b1[e]; }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] += (c + e < a.Cout) ? a.bias[c + e] : 0.f;
+            }
         }
         if (a.res_mode) {
-            size_t ro;
-            if (a.res_mode == 1) {
-                ro = (size_t)m * a.Cout + c;
-            } else {
-                const int ow = m % a.Wo, t = m / a.Wo;
-                const int oh = t % a.Ho, n = t / a.Ho;
-                ro = (((size_t)n * a.resH + (oh >> 1)) * a.resW + (ow >> 1)) * a.Cout + c;
-            }
-            const half8 rv = *reinterpret_cast<const half8*>(a.res + ro);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) x[e] += (float)rv[e];
+            for (int e = 0; e < 8; ++e) x[e] += (float)rres[i][e];
         }
         if (a.relu) {
 #pragma unroll

@@ -21,6 +21,8 @@ struct ProbenArgs {
     const double* vars;
     const int32_t* classes;
     const int32_t* offsets;
+    const int32_t* row_counts;
+    const int32_t* passthrough;
     int32_t B, K, max_rows, score_mode, box_mode;
     double thr, fw, fh;
     double* out_boxes;
@@ -44,9 +46,20 @@ __global__ __launch_bounds__(64) void proben_fuse_kernel(ProbenArgs a) {
     const int img = blockIdx.x;
     const int lane = threadIdx.x;
     const int beg = a.offsets[img];
-    const int n = a.offsets[img + 1] - beg;
+    const int n = a.row_counts ? a.row_counts[img] : a.offsets[img + 1] - beg;
     if (n > a.max_rows || n < 0) {
         if (lane == 0) a.out_counts[img] = -1;
+        return;
+    }
+    if (a.passthrough && a.passthrough[img]) {  // exactly one detector fired: rows pass through unchanged
+        for (int r = lane; r < n; r += 64) {
+            const size_t o = (size_t)beg + r;
+            for (int e = 0; e < 4; ++e) a.out_boxes[o * 4 + e] = a.boxes[o * 4 + e];
+            a.out_scores[o] = (float)a.scores[o];
+            a.out_classes[o] = (float)a.classes[o];
+            a.out_keep[o] = r;
+        }
+        if (lane == 0) a.out_counts[img] = n;
         return;
     }
     const int R = a.max_rows;
@@ -222,11 +235,94 @@ __global__ __launch_bounds__(64) void proben_fuse_kernel(ProbenArgs a) {
     if (lane == 0) a.out_counts[img] = m_out;
 }
 
+struct PackArgs {
+    const float* boxes[4];
+    const float* scores[4];
+    const int32_t* classes[4];
+    const float* probs[4];
+    const float* vars[4];
+    const int32_t* counts[4];
+    int nd, B, D, K, max_class, stride;
+    double* ob;
+    double* os;
+    double* op;
+    double* ov;
+    int32_t* oc;
+    int32_t* ooff;
+    int32_t* ocnt;
+    int32_t* osingle;
+};
+
+// one wavefront per image: ordered compaction of every detector's live rows (class <= max_class)
+__global__ __launch_bounds__(64) void proben_pack_kernel(PackArgs a) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    int written = 0, sources = 0;
+    for (int d = 0; d < a.nd; ++d) {
+        const int before = written;
+        const int c = min(a.counts[d][b], a.D);
+        for (int base = 0; base < c; base += 64) {
+            const int j = base + lane;
+            bool ok = false;
+            int cls = 0;
+            if (j < c) {
+                cls = a.classes[d][(size_t)b * a.D + j];
+                ok = cls <= a.max_class;
+            }
+            const unsigned long long m = __ballot(ok);
+            if (ok) {
+                const size_t src = (size_t)b * a.D + j;
+                const size_t dst = (size_t)b * a.stride + written + __popcll(m & pe::lanemask_lt());
+                for (int e = 0; e < 4; ++e) a.ob[dst * 4 + e] = (double)a.boxes[d][src * 4 + e];
+                a.os[dst] = (double)a.scores[d][src];
+                for (int k = 0; k < a.K; ++k) a.op[dst * a.K + k] = (double)a.probs[d][src * a.K + k];
+                a.ov[dst] = (double)a.vars[d][src];
+                a.oc[dst] = cls;
+            }
+            written += __popcll(m);
+        }
+        sources += written > before ? 1 : 0;
+    }
+    if (lane == 0) {
+        a.ooff[b] = b * a.stride;
+        a.ocnt[b] = written;
+        if (a.osingle) a.osingle[b] = sources == 1 ? 1 : 0;
+    }
+}
+
 }  // namespace
+
+extern "C" int pe_proben_pack_detections(const float* const* det_boxes_host, const float* const* det_scores_host,
+                                         const int32_t* const* det_classes_host, const float* const* det_probs_host,
+                                         const float* const* det_vars_host, const int32_t* const* det_counts_host,
+                                         int32_t num_detectors, int32_t num_images, int32_t det_stride,
+                                         int32_t num_classes, int32_t max_class, int32_t row_stride,
+                                         double* out_boxes, double* out_scores, double* out_probs, double* out_vars,
+                                         int32_t* out_classes, int32_t* out_offsets, int32_t* out_counts,
+                                         int32_t* out_single_source, void* stream) {
+    PE_CHECK_ARG(num_detectors >= 1 && num_detectors <= 4, "pe_proben_pack_detections: num_detectors %d", num_detectors);
+    PE_CHECK_ARG(row_stride >= num_detectors * det_stride, "pe_proben_pack_detections: row_stride %d < %d", row_stride,
+                 num_detectors * det_stride);
+    PE_CHECK_ARG(out_boxes && out_scores && out_probs && out_vars && out_classes && out_offsets && out_counts,
+                 "pe_proben_pack_detections: null output");
+    if (num_images == 0) return PE_OK;
+    PackArgs a{};
+    for (int d = 0; d < num_detectors; ++d) {
+        a.boxes[d] = det_boxes_host[d]; a.scores[d] = det_scores_host[d]; a.classes[d] = det_classes_host[d];
+        a.probs[d] = det_probs_host[d]; a.vars[d] = det_vars_host[d]; a.counts[d] = det_counts_host[d];
+        PE_CHECK_ARG(a.boxes[d] && a.scores[d] && a.classes[d] && a.probs[d] && a.vars[d] && a.counts[d],
+                     "pe_proben_pack_detections: null detector pointer");
+    }
+    a.nd = num_detectors; a.B = num_images; a.D = det_stride; a.K = num_classes; a.max_class = max_class;
+    a.stride = row_stride; a.ob = out_boxes; a.os = out_scores; a.op = out_probs; a.ov = out_vars; a.oc = out_classes;
+    a.ooff = out_offsets; a.ocnt = out_counts; a.osingle = out_single_source;
+    hipLaunchKernelGGL(proben_pack_kernel, dim3(num_images), dim3(64), 0, (hipStream_t)stream, a);
+    PE_CHECK_LAUNCH("pe_proben_pack_detections");
+    return PE_OK;
+}
 
 extern "C" int pe_proben_fuse_batch(const double* boxes, const double* scores, const double* probs,
                                     const double* variances, const int32_t* classes, const int32_t* offsets,
-                                    int32_t num_images, int32_t num_classes, int32_t max_rows_per_image,
+                                    const int32_t* row_counts, const int32_t* passthrough, int32_t num_images, int32_t num_classes, int32_t max_rows_per_image,
                                     int32_t score_mode, int32_t box_mode, double iou_thresh, double frame_w,
                                     double frame_h, double* out_boxes, float* out_scores, float* out_classes,
                                     int32_t* out_keep, int32_t* out_counts, void* stream) {
@@ -250,7 +346,7 @@ extern "C" int pe_proben_fuse_batch(const double* boxes, const double* scores, c
         pe::set_error("pe_proben_fuse_batch: %zu bytes of LDS needed (> 160 KiB); lower max_rows_per_image", lds);
         return PE_ERR_UNSUPPORTED;
     }
-    ProbenArgs a{boxes, scores, probs, variances, classes, offsets, num_images, num_classes, R,
+    ProbenArgs a{boxes, scores, probs, variances, classes, offsets, row_counts, passthrough, num_images, num_classes, R,
                  score_mode, box_mode, iou_thresh, frame_w, frame_h,
                  out_boxes, out_scores, out_classes, out_keep, out_counts};
     if (lds > 64 * 1024) {

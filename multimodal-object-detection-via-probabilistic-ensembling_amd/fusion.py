@@ -17,7 +17,7 @@ FRAME_W, FRAME_H = 640.0, 512.0  # class-band shift hard-coded by the reference 
 
 
 def fuse_batch(boxes, scores, probs, variances, classes, offsets, score_fusion="probEn", box_fusion="v-avg",
-               max_rows=None, iou_thresh=0.5, frame=(FRAME_W, FRAME_H)):
+               max_rows=None, iou_thresh=0.5, frame=(FRAME_W, FRAME_H), row_counts=None, passthrough=None):
     """Fuse B images in one launch.
 
     boxes f64 [Ntot,4], scores f64 [Ntot], probs f64 [Ntot,K], variances f64 [Ntot],
@@ -29,7 +29,7 @@ def fuse_batch(boxes, scores, probs, variances, classes, offsets, score_fusion="
     _lib.require_cuda(boxes, scores, probs, variances, classes, offsets)
     if score_fusion == "max" and box_fusion == "argmax":
         raise ValueError("('max','argmax') is the class-aware NMS route: use fusion()/nms_fuse_batch")
-    B = offsets.numel() - 1
+    B = offsets.numel() - (0 if row_counts is not None else 1)
     ntot = boxes.shape[0]
     K = probs.shape[1] if probs is not None and probs.dim() == 2 else 1
     boxes = boxes.contiguous().double()
@@ -39,6 +39,7 @@ def fuse_batch(boxes, scores, probs, variances, classes, offsets, score_fusion="
     classes = classes.contiguous().to(torch.int32)
     offsets = offsets.contiguous().to(torch.int32)
     if max_rows is None:
+        assert row_counts is None, "max_rows must be given with row_counts (avoids a host sync)"
         max_rows = int((offsets[1:] - offsets[:-1]).max().item()) if B > 0 else 1
     max_rows = max(int(max_rows), 1)
     dev = boxes.device
@@ -51,7 +52,7 @@ def fuse_batch(boxes, scores, probs, variances, classes, offsets, score_fusion="
     }
     st = _lib.lib().pe_proben_fuse_batch(
         _lib.ptr(boxes), _lib.ptr(scores), _lib.ptr(probs), _lib.ptr(variances), _lib.ptr(classes),
-        _lib.ptr(offsets), B, K, max_rows, SCORE_MODES[score_fusion], BOX_MODES[box_fusion],
+        _lib.ptr(offsets), _lib.ptr(row_counts), _lib.ptr(passthrough), B, K, max_rows, SCORE_MODES[score_fusion], BOX_MODES[box_fusion],
         float(iou_thresh), float(frame[0]), float(frame[1]),
         _lib.ptr(out["boxes"]), _lib.ptr(out["scores"]), _lib.ptr(out["classes"]), _lib.ptr(out["keep"]),
         _lib.ptr(out["counts"]), _lib.stream())
@@ -114,3 +115,45 @@ def fusion(method, info_1, info_2, info_3=""):
         raise RuntimeError("fusion: too many rows for one image")
     boxes = out["boxes"][:m].cpu().numpy()
     return [boxes[i] for i in range(m)], out["scores"][:m].cpu(), out["classes"][:m].cpu()
+
+
+def fuse_detections(dets, score_fusion="probEn", box_fusion="v-avg", max_class=2, iou_thresh=0.5):
+    """Device-to-device stage fusion: `dets` = the result dicts of 2 or 3 detectors run on the SAME batch
+    (rcnn.GeneralizedRCNN.forward_batch).  Packs their detections into ProbEn rows (classes <= max_class,
+    like the JSON writer demo_FLIR_save_predictions.py:148-155), applies the reference's per-image case
+    split (0 detectors -> nothing, 1 -> passthrough, >= 2 -> fusion; demo_probEn.py:237-267) and fuses.
+    No host synchronisation.  Returns a dict: boxes f64 [B*S,4], scores f32, classes f32, counts i32 [B],
+    offsets i32 [B], stride S = len(dets) * D."""
+    import ctypes
+    nd = len(dets)
+    B, D = dets[0]["scores"].shape
+    K = dets[0]["prob_score"].shape[2]
+    dev = dets[0]["scores"].device
+    S = nd * D
+
+    def arr(key):
+        return (ctypes.c_void_p * nd)(*[d[key].data_ptr() for d in dets])
+    ob = torch.empty((B * S, 4), dtype=torch.float64, device=dev)
+    os_ = torch.empty((B * S,), dtype=torch.float64, device=dev)
+    op = torch.empty((B * S, K), dtype=torch.float64, device=dev)
+    ov = torch.empty((B * S,), dtype=torch.float64, device=dev)
+    oc = torch.empty((B * S,), dtype=torch.int32, device=dev)
+    ooff = torch.empty((B,), dtype=torch.int32, device=dev)
+    ocnt = torch.empty((B,), dtype=torch.int32, device=dev)
+    osingle = torch.empty((B,), dtype=torch.int32, device=dev)
+    st = _lib.lib().pe_proben_pack_detections(arr("boxes"), arr("scores"), arr("classes"), arr("prob_score"), arr("vars"),
+                                             arr("counts"), nd, B, D, K, max_class, S, _lib.ptr(ob), _lib.ptr(os_),
+                                             _lib.ptr(op), _lib.ptr(ov), _lib.ptr(oc), _lib.ptr(ooff), _lib.ptr(ocnt),
+                                             _lib.ptr(osingle), _lib.stream())
+    _lib.check(st, "pe_proben_pack_detections")
+    if score_fusion == "max" and box_fusion == "argmax":
+        from .layers import nms_batched_raw
+        b32 = ob.float().view(B, S, 4)
+        keep, kcnt = nms_batched_raw(b32, os_.float().view(B, S), oc.view(B, S), ocnt, None, iou_thresh, 0, S)
+        # TODO(next round): passthrough images on this route still go through NMS
+        return {"keep": keep, "counts": kcnt, "boxes": ob, "scores": os_.float(), "classes": oc.float(),
+                "offsets": ooff, "stride": S, "nms_route": True}
+    out = fuse_batch(ob, os_, op, ov, oc, ooff, score_fusion, box_fusion, max_rows=S, iou_thresh=iou_thresh,
+                     row_counts=ocnt, passthrough=osingle)
+    out["offsets"], out["stride"], out["in_counts"] = ooff, S, ocnt
+    return out

@@ -9,6 +9,7 @@ import torch
 from . import _lib
 
 _scratch = {}
+PROFILE = None  # bench.py's roofline leg sets this to a list and gets one record per conv launch
 
 
 def _get_scratch(nbytes, device):
@@ -149,6 +150,15 @@ def conv2d_nhwc(x, weight, bias, *, kernel, stride=1, relu=False, residual=None,
                                        N, H, W, Cin, Cout, kernel, stride, int(relu), int(residual_mode), rh, rw,
                                        int(out_f32), int(cout_store), int(out_stride), _lib.stream())
     _lib.check(st, "pe_conv2d_nhwc_f16")
+    if PROFILE is not None:  # bench.py roofline leg: remember the launch so it can be replayed back-to-back
+        kk = {1: "1x1", 3: "3x3", 7: "stem7x7"}[kernel]
+        variant = f"conv_igemm_kernel<128,{64 if Cout <= 64 else 128},{kk}>"
+        cin_real = 3 if kernel == 7 else Cin
+        shape = f"N{N} {H}x{W} Cin{Cin} Cout{Cout} k{kernel} s{stride} res{residual_mode} f32{int(out_f32)}"
+        PROFILE.append({"variant": variant, "shape": shape, "flops": 2.0 * N * Ho * Wo * Cout * kernel * kernel * cin_real,
+                        "args": (x, weight, bias, residual, out, dict(kernel=kernel, stride=stride, relu=relu,
+                                 residual_mode=residual_mode, out_f32=out_f32, cout_store=cout_store,
+                                 out_stride=out_stride, cout=cout))})
     return out
 
 

@@ -142,7 +142,8 @@ def test_batched_nms_matches_oracle(L, n, ncls, thr):
     g = torch.Generator().manual_seed(n)
     b = rand_boxes(g, n, span=200.0 if n > 1000 else 600.0)
     s = torch.rand(n, generator=g)
-    s[::7] = s[1::7][: len(s[::7])]  # exact ties
+    if n > 14:
+        s[:-1:7] = s[1::7][: len(s[:-1:7])]  # exact ties
     c = torch.randint(0, ncls, (n,), generator=g)
     got = L.batched_nms(b.cuda(), s.cuda(), c.cuda(), thr).cpu().numpy()
     want = O.batched_nms_f32(b.numpy(), s.numpy(), c.numpy(), thr, device_type="cuda")
