@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=8)
     ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--conv-impl", type=int, default=2, help="1: register-staged conv kernel, 2: LDS-DMA conv kernel")
     ap.add_argument("--layers", type=str, default="", help="write a per-conv-launch table (shape, ms, TFLOP/s) to this file")
     return ap.parse_args()
 
@@ -164,6 +165,8 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world)
     from proben_amd.synthetic import synthetic_images
     models, sds = build_models(args.depth, dev)
+    from proben_amd import _lib
+    _lib.check(_lib.lib().pe_set_conv_impl(args.conv_impl), "pe_set_conv_impl")
     B = args.batch
     frames_t = torch.from_numpy(synthetic_images(B, seed=10 + rank)).to(dev)
     frames_rgb = torch.from_numpy(synthetic_images(B, seed=1000 + rank)).to(dev)

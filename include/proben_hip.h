@@ -111,6 +111,9 @@ int pe_conv2d_nhwc_f16(const void* input, const void* weight, const float* bias,
                        int32_t kernel, int32_t stride, int32_t relu, int32_t residual_mode,
                        int32_t res_h, int32_t res_w, int32_t out_f32, int32_t cout_store,
                        int32_t out_stride, void* stream);
+/* Implementation switch for A/B measurements: 1 = register-staged double-buffered kernel,
+ * 2 (default) = LDS-DMA (global_load_lds) kernel.  The 7x7 stem always uses 1.  Process-global. */
+int pe_set_conv_impl(int32_t impl);
 
 /* ---------------------------------------------------------------------------------------------
  * Front-end layout kernels.

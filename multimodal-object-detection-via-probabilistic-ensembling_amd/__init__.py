@@ -9,3 +9,18 @@ package: every compute entry point raises if the HIP library or a GPU is absent.
 __version__ = "0.1.0"
 
 from . import _lib  # noqa: F401
+from .config import CfgNode, get_cfg  # noqa: F401
+from .structures import Boxes, ImageList, Instances  # noqa: F401
+
+
+def __getattr__(name):  # heavier modules load lazily
+    if name == "DefaultPredictor":
+        from .predictor import DefaultPredictor
+        return DefaultPredictor
+    if name in ("FLIREvaluator", "inference_on_dataset"):
+        from . import evaluation
+        return getattr(evaluation, name)
+    if name == "GeneralizedRCNN":
+        from .rcnn import GeneralizedRCNN
+        return GeneralizedRCNN
+    raise AttributeError(name)

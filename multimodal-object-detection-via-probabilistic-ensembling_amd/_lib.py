@@ -17,6 +17,7 @@ SIGNATURES = {
     "pe_proben_pack_detections": [c_void_p] * 6 + [c_int] * 6 + [c_void_p] * 9,
     "pe_proben_fuse_batch": [c_void_p] * 8 + [c_int] * 5 + [c_double] * 3 + [c_void_p] * 5 + [c_void_p],
     "pe_conv2d_nhwc_f16": [c_void_p] * 5 + [c_int] * 14 + [c_void_p],
+    "pe_set_conv_impl": [c_int],
     "pe_preprocess_pack": [c_void_p] + [c_int] * 11 + [c_void_p] * 4,
     "pe_maxpool3x3s2_nhwc": [c_void_p] * 2 + [c_int] * 4 + [c_void_p],
     "pe_subsample2_nhwc": [c_void_p] * 2 + [c_int] * 4 + [c_void_p],

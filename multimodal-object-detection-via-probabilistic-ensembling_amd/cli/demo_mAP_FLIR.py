@@ -1,0 +1,40 @@
+"""Counterpart of demo/FLIR/demo_mAP_FLIR.py: single-detector mAP through DefaultPredictor ->
+build_detection_test_loader -> inference_on_dataset -> FLIREvaluator.
+
+    python -m proben_amd.cli.demo_mAP_FLIR --dataset_path DATA/FLIR/val --fusion_method thermal_only --model_path m.pth
+"""
+import json
+import os
+
+import torch
+
+from ..data import DatasetCatalog, build_detection_test_loader, read_image, register_coco_instances, resize_shortest_edge_shape
+from ..evaluation import FLIREvaluator, inference_on_dataset
+from ..opt import config_parser
+from .save_predictions import build_cfg
+
+
+def main(cmd=None):
+    from ..predictor import DefaultPredictor
+    args = config_parser(cmd)
+    val_json = os.path.join(args.dataset_path, "FLIR_thermal_RGBT_pairs_val.json")
+    register_coco_instances(args.dataset_name, {}, val_json, os.path.join(args.dataset_path, "thermal_8_bit"))
+    dicts = DatasetCatalog.get(args.dataset_name)
+    cfg = build_cfg(args)
+    cfg.DATASETS.TEST = (args.dataset_name,)
+    predictor = DefaultPredictor(cfg)
+
+    def mapper(d):
+        img = read_image(d["file_name"], cfg.INPUT.FORMAT)
+        return {"image_np": img, "height": d["height"], "width": d["width"], "image_id": d["image_id"], "file_name": d["file_name"]}
+
+    def model(inputs):
+        return predictor.predict_batch([x["image_np"] for x in inputs])
+    ev = FLIREvaluator(args.dataset_name, cfg, False, output_dir=args.outfolder)
+    res = inference_on_dataset(model, build_detection_test_loader(dicts, mapper), ev)
+    print(json.dumps(res, indent=1))
+    return res
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,274 @@
+// Implicit-GEMM convolution, second generation: LDS-DMA staging (global_load_lds, 16 B / lane) into an
+// XOR-swizzled, unpadded LDS image, single LDS stage, 3-4 workgroups per CU.
+//
+// Same contract and epilogue as csrc/conv_igemm.hip (which keeps the 7x7 stem); same reference rows replaced
+// (layers/wrappers.py:62-98 + layers/batch_norm.py:45-65 + relu_ + backbone/resnet.py:205-221 residual add +
+// backbone/fpn.py:129-137 top-down add; roi_heads/box_head.py:73-81 FC with H = W = 1).
+//
+// Why: with register staging + padded double-buffered LDS (74 KB) only 2 workgroups fit a CU, and each one
+// exposes a full HBM/L2 round trip per K-step (measured r01: 3x3 res4 525 TFLOP/s, memory-bound 1x1 at
+// 1.5-1.8 TB/s).  Here the A (gathered pixels) and B (weights) K-slabs go HBM -> LDS without touching VGPRs:
+//   * one `global_load_lds_dwordx4` fills 8 rows x 128 B (1 KiB, lane-linear) per wavefront instruction;
+//   * the LDS image is [row][8 chunks of 16 B] with chunk p of row r holding K-chunk p ^ ((r >> 1) & 7):
+//     the swizzle is applied to the per-lane SOURCE address (the DMA destination must stay linear) and to
+//     the fragment reads, which makes every ds_read_b128 of an MFMA operand bank-conflict-free;
+//   * out-of-image taps (3x3 halo) and rows beyond M read a 16-byte zero page instead of branching;
+//   * 32 KiB of LDS per workgroup (+ a two-pass fp32 epilogue staging of 33 KiB that reuses it) lets 4
+//     workgroups share a CU, so one workgroup's DMA wait overlaps three others' MFMAs.
+#include <hip/hip_fp16.h>
+
+#include "common.h"
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float float16v __attribute__((ext_vector_type(16)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+
+constexpr int BK = 64;       // halfs per K-step = one 128-byte LDS row
+constexpr int ROW_B = 128;   // bytes per LDS row
+constexpr int MODE_1X1 = 0, MODE_3X3 = 1;
+
+__device__ __attribute__((aligned(16))) unsigned int g_zero_page[4] = {0, 0, 0, 0};
+
+struct Conv2Args {
+    const _Float16* in;
+    const _Float16* wgt;
+    const float* bias;
+    const _Float16* res;
+    void* out;
+    int N, H, W, Cin;
+    int Ho, Wo, Cout;
+    int stride;
+    int M, K;
+    int relu, res_mode;
+    int resH, resW;
+    int out_f32, cout_store, out_stride;
+    int tiles_m, tiles_n;
+};
+
+typedef const void __attribute__((address_space(1)))* gptr_t;
+typedef void __attribute__((address_space(3)))* lptr_t;
+
+template <int BM, int BN, int MODE>
+__global__ __launch_bounds__(256, 3) void conv_igemm2_kernel(Conv2Args a) {
+    constexpr int WM = BM / 2, WN = BN / 2;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int A_INSTR = BM / 32;  // DMA instructions per wave per K-step for A (8 rows each, 4 waves)
+    constexpr int B_INSTR = BN / 32;
+    constexpr int A_BYTES = BM * ROW_B;
+    constexpr int EP_ROWS = BM / 2;   // epilogue handles the tile in two passes of BM/2 rows
+    constexpr int EP_ROW = BN + 4;    // floats
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int nwg = a.tiles_m * a.tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_n = bid % a.tiles_n, tile_m = bid / a.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lrow = lane >> 3, lp = lane & 7;  // row within the 8-row DMA group, physical 16-B chunk
+
+    // ---- per-lane DMA descriptors ----
+    const _Float16* a_base[A_INSTR];
+    int a_oh[A_INSTR], a_ow[A_INSTR], a_coff[A_INSTR];
+    bool a_ok[A_INSTR];
+#pragma unroll
+    for (int i = 0; i < A_INSTR; ++i) {
+        const int r = (wave * A_INSTR + i) * 8 + lrow;
+        const int m = m0 + r;
+        a_ok[i] = m < a.M;
+        const int mm = a_ok[i] ? m : 0;
+        const int ow = mm % a.Wo, t = mm / a.Wo;
+        const int oh = t % a.Ho, n = t / a.Ho;
+        a_oh[i] = oh * a.stride;
+        a_ow[i] = ow * a.stride;
+        a_base[i] = a.in + (size_t)n * a.H * a.W * a.Cin;
+        a_coff[i] = (lp ^ ((r >> 1) & 7)) * 8;  // logical K-chunk held by this lane's physical slot
+    }
+    const _Float16* b_src[B_INSTR];
+#pragma unroll
+    for (int i = 0; i < B_INSTR; ++i) {
+        const int r = (wave * B_INSTR + i) * 8 + lrow;
+        const int n = n0 + r;
+        b_src[i] = (n < a.Cout) ? a.wgt + (size_t)n * a.K + (lp ^ ((r >> 1) & 7)) * 8 : nullptr;
+    }
+    const _Float16* zero = reinterpret_cast<const _Float16*>(g_zero_page);
+
+    float16v acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // fragment read offsets: row = wave tile base + (lane & 31); K-chunk (2*ks + (lane >> 5)) ^ swizzle(row)
+    const int frow = lane & 31, fsw = (frow >> 1) & 7, fkh = lane >> 5;
+    const unsigned char* la = smem + (wm * WM + frow) * ROW_B;
+    const unsigned char* lb = smem + A_BYTES + (wn * WN + frow) * ROW_B;
+
+    const int nk = a.K / BK;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int k0 = kt * BK;
+        // ---- LDS-DMA: global -> LDS, no VGPR round trip ----
+        int kh = 0, kw = 0, c0 = k0;
+        if (MODE == MODE_3X3) {
+            const int tap = k0 / a.Cin;
+            c0 = k0 - tap * a.Cin;
+            kh = tap / 3 - 1;
+            kw = tap - (tap / 3) * 3 - 1;
+        }
+#pragma unroll
+        for (int i = 0; i < A_INSTR; ++i) {
+            const int ih = a_oh[i] + kh, iw = a_ow[i] + kw;
+            bool ok = a_ok[i];
+            if (MODE == MODE_3X3) ok = ok && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+            const _Float16* p = ok ? a_base[i] + ((size_t)ih * a.W + iw) * a.Cin + c0 + a_coff[i] : zero;
+            __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(smem + (wave * A_INSTR + i) * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < B_INSTR; ++i) {
+            const _Float16* p = b_src[i] ? b_src[i] + k0 : zero;
+            __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(smem + A_BYTES + (wave * B_INSTR + i) * 1024), 16, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        // ---- fragments + MFMA ----
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            const int ch = ((ks * 2 + fkh) ^ fsw) << 4;
+            half8 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const half8*>(la + i * 32 * ROW_B + ch);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const half8*>(lb + j * 32 * ROW_B + ch);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();  // every wave is done reading before the next K-step's DMA lands
+    }
+
+    // ---- epilogue: two passes of BM/2 rows through LDS (fp32), vectorised bias / residual / ReLU / store ----
+    constexpr int VEC_PER_ROW = BN / 8;
+    constexpr int NV = EP_ROWS * VEC_PER_ROW / 256;
+    float* ep = reinterpret_cast<float*>(smem);
+    const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        half8 rres[NV];
+        if (a.res_mode) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int v = tid + i * 256;
+                const int r = v / VEC_PER_ROW, c8 = (v - r * VEC_PER_ROW) * 8;
+                const int m = m0 + pass * EP_ROWS + r, c = n0 + c8;
+                rres[i] = zero8;
+                if (m < a.M && c < a.cout_store) {
+                    size_t ro;
+                    if (a.res_mode == 1) {
+                        ro = (size_t)m * a.Cout + c;
+                    } else {
+                        const int ow = m % a.Wo, t = m / a.Wo;
+                        const int oh = t % a.Ho, n = t / a.Ho;
+                        ro = (((size_t)n * a.resH + (oh >> 1)) * a.resW + (ow >> 1)) * a.Cout + c;
+                    }
+                    rres[i] = *reinterpret_cast<const half8*>(a.res + ro);
+                }
+            }
+        }
+        if (wm == pass) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int r = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                        const int c = wn * WN + j * 32 + (lane & 31);
+                        ep[r * EP_ROW + c] = acc[i][j][e];
+                    }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int v = tid + i * 256;
+            const int r = v / VEC_PER_ROW, c8 = (v - r * VEC_PER_ROW) * 8;
+            const int m = m0 + pass * EP_ROWS + r, c = n0 + c8;
+            if (m >= a.M || c >= a.cout_store) continue;
+            const float4v x0 = *reinterpret_cast<const float4v*>(ep + r * EP_ROW + c8);
+            const float4v x1 = *reinterpret_cast<const float4v*>(ep + r * EP_ROW + c8 + 4);
+            float x[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+            if (a.bias) {
+                if (c + 8 <= a.Cout) {
+                    const float4v b0 = *reinterpret_cast<const float4v*>(a.bias + c);
+                    const float4v b1 = *reinterpret_cast<const float4v*>(a.bias + c + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { x[e] += b0[e]; x[e + 4] += b1[e]; }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) x[e] += (c + e < a.Cout) ? a.bias[c + e] : 0.f;
+                }
+            }
+            if (a.res_mode) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] += (float)rres[i][e];
+            }
+            if (a.relu) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] = fmaxf(x[e], 0.f);
+            }
+            if (a.out_f32) {
+                float* o = reinterpret_cast<float*>(a.out) + (size_t)m * a.out_stride + c;
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (c + e < a.cout_store) o[e] = x[e];
+            } else {
+                half8 h;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) h[e] = (_Float16)x[e];
+                *reinterpret_cast<half8*>(reinterpret_cast<_Float16*>(a.out) + (size_t)m * a.out_stride + c) = h;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <int BM, int BN, int MODE>
+int launch2(const Conv2Args& a0, hipStream_t st) {
+    Conv2Args a = a0;
+    a.tiles_m = pe::ceil_div(a.M, BM);
+    a.tiles_n = pe::ceil_div(a.Cout, BN);
+    constexpr size_t stage = (size_t)(BM + BN) * ROW_B;
+    constexpr size_t epi = (size_t)(BM / 2) * (BN + 4) * 4;
+    constexpr size_t lds = stage > epi ? stage : epi;
+    hipLaunchKernelGGL((conv_igemm2_kernel<BM, BN, MODE>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds, st, a);
+    PE_CHECK_LAUNCH("pe_conv2d_nhwc_f16(v2)");
+    return PE_OK;
+}
+
+}  // namespace
+
+namespace pe {
+// called from pe_conv2d_nhwc_f16 (conv_igemm.hip) for the 1x1 / 3x3 cases
+int conv2_dispatch(const void* in, const void* wgt, const float* bias, const void* res, void* out, int N, int H, int W,
+                   int Cin, int Cout, int Ho, int Wo, int K, int M, int mode3x3, int stride, int relu, int res_mode,
+                   int resH, int resW, int out_f32, int cout_store, int out_stride, hipStream_t st) {
+    Conv2Args a{};
+    a.in = (const _Float16*)in; a.wgt = (const _Float16*)wgt; a.bias = bias; a.res = (const _Float16*)res; a.out = out;
+    a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout; a.stride = stride; a.M = M; a.K = K;
+    a.relu = relu; a.res_mode = res_mode; a.resH = resH; a.resW = resW; a.out_f32 = out_f32;
+    a.cout_store = cout_store; a.out_stride = out_stride;
+    const bool narrow = Cout <= 64;
+    if (mode3x3) return narrow ? launch2<128, 64, MODE_3X3>(a, st) : launch2<128, 128, MODE_3X3>(a, st);
+    return narrow ? launch2<128, 64, MODE_1X1>(a, st) : launch2<128, 128, MODE_1X1>(a, st);
+}
+}  // namespace pe

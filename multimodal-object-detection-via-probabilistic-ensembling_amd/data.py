@@ -1,0 +1,125 @@
+"""The slice of the reference's data layer the inference path touches:
+dataset / metadata catalogs and COCO-json registration (detectron2/data/catalog.py,
+data/datasets/register_coco.py:14, coco.py:29-195), the contiguous inference shards
+(data/samplers/distributed_sampler.py:172-199), the batch-1 test loader (data/build.py:342-386) and the
+ResizeShortestEdge size rule (data/transforms/transform_gen.py:192-213)."""
+import json
+import os
+import types
+
+import numpy as np
+import torch
+
+from . import comm
+
+
+class _Metadata(types.SimpleNamespace):
+    def get(self, key, default=None):
+        return getattr(self, key, default)
+
+
+class _MetadataCatalog:
+    _store = {}
+
+    @classmethod
+    def get(cls, name):
+        if name not in cls._store:
+            cls._store[name] = _Metadata(name=name)
+        return cls._store[name]
+
+
+class _DatasetCatalog:
+    _fns = {}
+
+    @classmethod
+    def register(cls, name, fn):
+        cls._fns[name] = fn
+
+    @classmethod
+    def get(cls, name):
+        return cls._fns[name]()
+
+    @classmethod
+    def list(cls):
+        return list(cls._fns)
+
+
+MetadataCatalog = _MetadataCatalog
+DatasetCatalog = _DatasetCatalog
+
+
+def load_coco_json(json_file, image_root, dataset_name=None):
+    """COCO json -> list of dataset dicts {file_name, height, width, image_id, annotations[...]}; fills
+    thing_classes / thing_dataset_id_to_contiguous_id of the dataset's metadata (sorted category ids)."""
+    with open(json_file) as f:
+        d = json.load(f)
+    cats = sorted(d.get("categories", []), key=lambda c: c["id"])
+    id_map = {c["id"]: i for i, c in enumerate(cats)}
+    if dataset_name is not None:
+        meta = MetadataCatalog.get(dataset_name)
+        meta.thing_classes = [c["name"] for c in cats]
+        meta.thing_dataset_id_to_contiguous_id = id_map
+    anns = {}
+    for a in d.get("annotations", []):
+        anns.setdefault(a["image_id"], []).append(a)
+    out = []
+    for im in d["images"]:
+        rec = {"file_name": os.path.join(image_root, im["file_name"]), "height": im["height"], "width": im["width"],
+               "image_id": im["id"], "annotations": []}
+        for a in anns.get(im["id"], []):
+            if a.get("ignore", 0) != 0:
+                continue
+            rec["annotations"].append({"bbox": a["bbox"], "bbox_mode": 1, "iscrowd": a.get("iscrowd", 0),
+                                       "category_id": id_map.get(a["category_id"], a["category_id"])})
+        out.append(rec)
+    return out
+
+
+def register_coco_instances(name, metadata, json_file, image_root):
+    DatasetCatalog.register(name, lambda: load_coco_json(json_file, image_root, name))
+    meta = MetadataCatalog.get(name)
+    meta.json_file, meta.image_root, meta.evaluator_type = json_file, image_root, "coco"
+    for k, v in metadata.items():
+        setattr(meta, k, v)
+
+
+def resize_shortest_edge_shape(h, w, short_edge_length=800, max_size=1333):
+    """ResizeShortestEdge.get_transform: short side -> 800 capped so the long side <= 1333, round half up."""
+    size = short_edge_length
+    scale = size * 1.0 / min(h, w)
+    if h < w:
+        newh, neww = size, scale * w
+    else:
+        newh, neww = scale * h, size
+    if max(newh, neww) > max_size:
+        scale = max_size * 1.0 / max(newh, neww)
+        newh, neww = newh * scale, neww * scale
+    return int(newh + 0.5), int(neww + 0.5)
+
+
+class InferenceSampler:
+    """Contiguous per-rank index blocks of ceil(N / W)."""
+
+    def __init__(self, size, rank=None, world=None):
+        self._range = comm.shard_range(size, rank, world)
+
+    def __iter__(self):
+        yield from self._range
+
+    def __len__(self):
+        return len(self._range)
+
+
+def read_image(file_name, format="BGR"):
+    """PIL decode -> HWC uint8 in the requested channel order (detection_utils.py:37-96, 3-channel case)."""
+    from PIL import Image
+    with open(file_name, "rb") as f:
+        img = np.asarray(Image.open(f).convert("RGB"))
+    return img[:, :, ::-1].copy() if format == "BGR" else img
+
+
+def build_detection_test_loader(dataset_dicts, mapper, rank=None, world=None):
+    """Batch-1, rank-sharded, in-order loader of mapped dataset dicts (list of lists, like the reference's
+    trivial_batch_collator)."""
+    idx = list(InferenceSampler(len(dataset_dicts), rank, world))
+    return [[mapper(dataset_dicts[i])] for i in idx]

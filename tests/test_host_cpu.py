@@ -1,0 +1,149 @@
+"""Host-side logic on CPU: evaluator vs the reference's vendored COCOeval fixture, config, resize rule,
+shards, containers, J1 schema, class whitelist, KAIST rows."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import proben_amd  # noqa: F401
+from proben_amd import data, evaluation, late_fusion
+from proben_amd.cli import demo_LAMR_KAIST
+from proben_amd.structures import Boxes, ImageList, Instances
+
+
+def test_cocoeval_matches_reference_vendored_evaluator(golden_dir):
+    z = json.load(open(os.path.join(golden_dir, "cocoeval_case.json")))
+    ev = evaluation.COCOevalBBox(z["gt"], z["dets"])
+    ev.evaluate()
+    ev.accumulate()
+    stats = ev.summarize(printer=None)
+    np.testing.assert_allclose(stats, z["stats"], rtol=0, atol=1e-12)
+    prec = ev.eval["precision"]
+    assert float(prec[prec > -1].sum()) == pytest.approx(z["precision_sum"], abs=1e-9)
+    rec = ev.eval["recall"]
+    assert float(rec[rec > -1].sum()) == pytest.approx(z["recall_sum"], abs=1e-9)
+    for k, want in enumerate(z["per_class_ap"]):
+        p = prec[:, :, k, 0, -1]
+        p = p[p > -1]
+        assert float(np.mean(p)) == pytest.approx(want, abs=1e-12)
+
+
+def test_flir_evaluator_end_to_end(tmp_path, golden_dir):
+    z = json.load(open(os.path.join(golden_dir, "cocoeval_case.json")))
+    gt_path = tmp_path / "FLIR_thermal_RGBT_pairs_val.json"
+    json.dump(z["gt"], open(gt_path, "w"))
+    data.register_coco_instances("flir_test", {}, str(gt_path), str(tmp_path))
+    data.DatasetCatalog.get("flir_test")
+    ev = evaluation.FLIREvaluator("flir_test", proben_amd.get_cfg(), False, output_dir=str(tmp_path))
+    # detections arrive as Instances in CONTIGUOUS class ids (0..2); the evaluator maps them back to dataset ids
+    by_img = {}
+    for d in z["dets"]:
+        by_img.setdefault(d["image_id"], []).append(d)
+    for iid, ds in by_img.items():
+        inst = Instances((512, 640))
+        b = torch.tensor([d["bbox"] for d in ds], dtype=torch.float64)
+        b[:, 2:] += b[:, :2]
+        inst.pred_boxes = Boxes(b.float())
+        inst.scores = torch.tensor([d["score"] for d in ds])
+        inst.pred_classes = torch.tensor([d["category_id"] - 1 for d in ds])
+        ev.process([{"image_id": iid}], [{"instances": inst}])
+    res = ev.evaluate()["bbox"]
+    assert res["AP50"] == pytest.approx(z["stats"][1] * 100, abs=0.05)   # boxes went through float32
+    assert set(res) >= {"AP", "AP50", "AP75", "AP-person", "AP-bicycle", "AP-car"}
+
+
+def test_instances_to_coco_json_class_whitelist():
+    inst = Instances((512, 640))
+    inst.pred_boxes = Boxes(torch.tensor([[0, 0, 10, 20.0]] * 6))
+    inst.scores = torch.linspace(0.9, 0.4, 6)
+    inst.pred_classes = torch.tensor([0, 3, 5, 7, 16, 2])   # 3 (ProbEn "background") is dropped, 5/7 -> 2
+    out = evaluation.instances_to_coco_json(inst, 7)
+    assert [o["category_id"] for o in out] == [0, 2, 2, 16, 2]
+    assert out[0]["bbox"] == [0.0, 0.0, 10.0, 20.0] and out[0]["image_id"] == 7
+
+
+def test_config_merges_reference_style_yaml(tmp_path):
+    (tmp_path / "base.yaml").write_text("MODEL:\n  RESNETS:\n    DEPTH: 50\n  RPN:\n    BBOX_REG_WEIGHTS: (1.0, 1.0, 1.0, 1.0)\n")
+    (tmp_path / "child.yaml").write_text('_BASE_: "base.yaml"\nMODEL:\n  RESNETS:\n    DEPTH: 101\n  WEIGHTS: "x.pth"\n')
+    cfg = proben_amd.get_cfg()
+    cfg.merge_from_file(str(tmp_path / "child.yaml"))
+    assert cfg.MODEL.RESNETS.DEPTH == 101 and cfg.MODEL.WEIGHTS == "x.pth"
+    assert cfg.MODEL.RPN.BBOX_REG_WEIGHTS == (1.0, 1.0, 1.0, 1.0)
+    cfg.MODEL.ROI_BOX_HEAD.DROP_OUT = True  # scripts add new keys on the fly (demo_FLIR_save_predictions.py:53)
+    cfg.merge_from_list(["MODEL.ROI_HEADS.NUM_CLASSES", 3])
+    assert cfg.clone().MODEL.ROI_HEADS.NUM_CLASSES == 3
+    from proben_amd.predictor import detector_config_from_cfg
+    assert detector_config_from_cfg(cfg).num_classes == 3
+
+
+def test_predictor_refuses_cpu_device():
+    cfg = proben_amd.get_cfg()
+    cfg.MODEL.DEVICE = "cpu"
+    cfg.MODEL.WEIGHTS = "synthetic://1"
+    with pytest.raises(proben_amd._lib.HipLibraryError):
+        proben_amd.DefaultPredictor(cfg)
+
+
+def test_resize_shortest_edge_rule():
+    assert data.resize_shortest_edge_shape(512, 640) == (800, 1000)       # FLIR / KAIST
+    assert data.resize_shortest_edge_shape(480, 640) == (800, 1067)
+    assert data.resize_shortest_edge_shape(100, 1000) == (133, 1333)      # capped by MAX_SIZE_TEST
+    assert data.resize_shortest_edge_shape(640, 512) == (1000, 800)
+
+
+def test_inference_sampler_shards():
+    for n, w in [(10, 4), (8, 8), (3, 8), (0, 2), (1366, 8)]:
+        parts = [list(data.InferenceSampler(n, r, w)) for r in range(w)]
+        assert sum(parts, []) == list(range(n))                           # contiguous, ordered, complete
+        shard = (n - 1) // w + 1 if n else 0
+        assert all(len(p) <= shard for p in parts)
+
+
+def test_boxes_and_instances_contract():
+    b = Boxes(torch.tensor([[-5.0, 2.0, 700.0, 600.0], [1.0, 1.0, 1.0, 5.0]]))
+    b.clip((512, 640))
+    assert b.tensor.tolist() == [[0.0, 2.0, 640.0, 512.0], [1.0, 1.0, 1.0, 5.0]]
+    assert b.nonempty().tolist() == [True, False] and b.area().tolist() == [640.0 * 510.0, 0.0]
+    b.scale(0.5, 2.0)
+    assert b.tensor[0].tolist() == [0.0, 4.0, 320.0, 1024.0]
+    assert Boxes([]).tensor.shape == (0, 4) and len(Boxes.cat([b, b])) == 4
+    inst = Instances((10, 20))
+    inst.pred_boxes = b
+    inst.scores = torch.tensor([0.9, 0.1])
+    with pytest.raises(AssertionError):
+        inst.pred_classes = torch.tensor([1])                             # length check (instances.py)
+    # tests/test_instances.py:9-21: int indexing keeps a length-1 Instances, out of range raises
+    assert len(inst[1]) == 1 and len(inst[-1]) == 1
+    with pytest.raises(IndexError):
+        inst[2]
+    assert len(Instances.cat([inst, inst])) == 4 and inst.has("scores") and not inst.has("vars")
+    with pytest.raises(AttributeError):
+        inst.nothing
+    il = ImageList.from_tensors([torch.ones(3, 5, 7), torch.ones(3, 6, 4)], 32)
+    assert il.tensor.shape == (2, 3, 32, 32) and il.image_sizes == [(5, 7), (6, 4)] and float(il.tensor[0, 0, 5:].sum()) == 0
+
+
+def test_j1_prediction_schema(tmp_path):
+    inst = Instances((512, 640))
+    inst.pred_boxes = Boxes(torch.tensor([[1.0, 2, 30, 40], [5.0, 6, 70, 80], [9.0, 9, 20, 20]]))
+    inst.scores = torch.tensor([0.9, 0.8, 0.7])
+    inst.pred_classes = torch.tensor([0, 5, 2])      # class 5 (> 2) is dropped like :148-155
+    inst.class_logits = torch.rand(3, 4)
+    inst.prob_score = torch.rand(3, 3)
+    inst.vars = torch.rand(3, 1)
+    pred = late_fusion.predictions_to_j1(["a.jpeg"], [11], [inst])
+    assert list(pred) == late_fusion.J1_KEYS
+    assert pred["classes"] == [[0, 2]] and len(pred["boxes"][0]) == 2 and len(pred["vars"][0][0]) == 1
+    assert len(pred["class_logits"][0][0]) == 4 and len(pred["probs"][0][0]) == 3 and pred["image_id"] == [11]
+    p = tmp_path / "val_thermal_only_predictions.json"
+    late_fusion.write_j1(str(p), pred)
+    assert late_fusion.read_j1(str(p)) == json.loads(json.dumps(pred))
+
+
+def test_kaist_rows():
+    inst = Instances((512, 640))
+    inst.pred_boxes = Boxes(torch.tensor([[10.0, 20.0, 30.0, 60.0]]))
+    inst.scores = torch.tensor([0.5])
+    assert demo_LAMR_KAIST.kaist_rows(0, inst) == ["1,10.0000,20.0000,20.0000,40.0000,0.50000000"]

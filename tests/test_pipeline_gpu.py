@@ -1,0 +1,97 @@
+"""Predictor, late-fusion driver (P5 case split) and the device-to-device stage fusion on the GPU."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _j1_from_synth(per_image, d):
+    out = {k: [] for k in ["image", "boxes", "scores", "classes", "image_id", "class_logits", "probs", "vars"]}
+    for i, infos in enumerate(per_image):
+        x = infos[d]
+        out["image"].append(f"im{i}.jpeg")
+        out["boxes"].append(np.asarray(x["bbox"]).tolist())
+        out["scores"].append(np.asarray(x["score"]).tolist())
+        out["classes"].append(np.asarray(x["class"]).tolist())
+        out["image_id"].append(1000 + i)
+        out["class_logits"].append(np.asarray(x["prob"]).tolist())
+        out["probs"].append(np.asarray(x["prob"]).tolist())
+        out["vars"].append(np.asarray(x["vars"]).tolist())
+    return out
+
+
+@pytest.mark.parametrize("kdet", [2, 3])
+@pytest.mark.parametrize("method", [("probEn", "v-avg"), ("avg", "s-avg"), ("max", "argmax")])
+def test_late_fusion_case_split_matches_oracle(kdet, method):
+    """demo_probEn.py:237-267: 0 detectors -> skip, 1 -> passthrough, 2/3 -> fusion of the non-empty lists."""
+    import proben_amd  # noqa: F401
+    from oracle import proben as O
+    from proben_amd import late_fusion as LF
+    from proben_amd.synthetic import synth_detections
+    per_image = synth_detections(24, seed=40 + kdet, kdet=kdet, nmax=30)
+    empty = {"bbox": np.zeros((0, 4)), "score": np.zeros(0), "class": np.zeros(0, int), "prob": np.zeros((0, 3)), "vars": np.zeros((0, 1))}
+    per_image[0] = [empty] * kdet                                       # nobody fired
+    per_image[1] = [per_image[1][0]] + [empty] * (kdet - 1)              # only detector 1
+    per_image[2] = [empty] * (kdet - 1) + [per_image[2][-1]]             # only the last detector
+    if kdet == 3:
+        per_image[3] = [empty, per_image[3][1], per_image[3][2]]        # two of three
+    dets = [_j1_from_synth(per_image, d) for d in range(kdet)]
+    got = LF.late_fusion(dets, list(method))
+    for i, infos in enumerate(per_image):
+        live = [x for x in infos if len(x["score"])]
+        if not live:
+            assert got[i] is None
+            continue
+        b, s, c = got[i]
+        if len(live) == 1:
+            np.testing.assert_array_equal(np.asarray(b), live[0]["bbox"])
+            np.testing.assert_array_equal(s.numpy(), live[0]["score"].astype(np.float32))
+            continue
+        wb, ws, wc = O.fusion(list(method), *live)
+        assert len(b) == len(wb), (i, method)
+        np.testing.assert_array_equal(c.numpy(), wc)
+        np.testing.assert_allclose(s.numpy(), ws, rtol=1e-6, equal_nan=True)
+        np.testing.assert_allclose(np.asarray(b, dtype=np.float64), np.asarray(wb, dtype=np.float64), rtol=1e-6, atol=1e-6, equal_nan=True)
+
+
+def test_predictor_and_device_stage_fusion():
+    """DefaultPredictor contract + fuse_detections (device-to-device) == JSON-style host route."""
+    import proben_amd
+    from proben_amd import fusion as F
+    from proben_amd import late_fusion as LF
+    from proben_amd.synthetic import synthetic_images
+    preds = []
+    for seed in (1, 2):
+        cfg = proben_amd.get_cfg()
+        cfg.MODEL.RESNETS.DEPTH = 50
+        cfg.MODEL.ROI_HEADS.NUM_CLASSES = 3
+        cfg.MODEL.ROI_HEADS.SCORE_THRESH_TEST = 0.5
+        cfg.MODEL.ROI_BOX_HEAD.OUTPUT_LOGITS = True
+        cfg.MODEL.ROI_HEADS.ENABLE_GAUSSIANNLLOSS = True
+        cfg.MODEL.WEIGHTS = f"synthetic://{seed}"
+        preds.append(proben_amd.DefaultPredictor(cfg))
+    frames = synthetic_images(3, height=256, width=320, seed=5)
+    one = preds[0](frames[0])["instances"]
+    assert one.image_size == (256, 320) and one.has("vars") and one.has("prob_score") and one.has("class_logits")
+    dets, j1 = [], []
+    for p in preds:
+        d = p.model.forward_batch([torch.from_numpy(f).cuda() for f in frames], out_sizes=[(256, 320)] * 3, resize_to=(800, 1000))
+        dets.append(d)
+        insts = [o["instances"] for o in p.model.to_instances(d)]
+        j1.append(LF.predictions_to_j1([f"im{i}.jpeg" for i in range(3)], list(range(3)), insts))
+    batch0 = [o["instances"] for o in preds[0].predict_batch(list(frames))]
+    assert torch.equal(batch0[0].pred_boxes.tensor, one.pred_boxes.tensor)     # batch == single image
+    fused = F.fuse_detections(dets, "probEn", "v-avg")
+    host = LF.late_fusion(j1, ["probEn", "v-avg"])
+    cnt, off = fused["counts"].cpu().numpy(), fused["offsets"].cpu().numpy()
+    for i in range(3):
+        if host[i] is None:
+            assert cnt[i] == 0
+            continue
+        b, s, c = host[i]
+        sl = slice(off[i], off[i] + cnt[i])
+        assert cnt[i] == len(s)
+        np.testing.assert_array_equal(fused["classes"][sl].cpu().numpy(), c.numpy())
+        np.testing.assert_allclose(fused["scores"][sl].cpu().numpy(), s.numpy(), rtol=1e-6, equal_nan=True)
+        np.testing.assert_allclose(fused["boxes"][sl].cpu().numpy(), np.asarray(b), rtol=1e-9, atol=1e-9, equal_nan=True)
