@@ -57,7 +57,7 @@ def make_step(models, frames_t, frames_rgb, world, rank):
     from proben_amd import fusion as F
     B = frames_t.shape[0]
     out_sizes = [(512, 640)] * B
-    ft, fr = list(frames_t), list(frames_rgb)
+    ft, fr = frames_t, frames_rgb  # [B,512,640,3] uint8 batches, one preprocess launch each
 
     def step():
         det_t = models[0].forward_batch(ft, out_sizes=out_sizes, resize_to=(800, 1000))

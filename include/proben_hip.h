@@ -112,8 +112,12 @@ int pe_conv2d_nhwc_f16(const void* input, const void* weight, const float* bias,
                        int32_t res_h, int32_t res_w, int32_t out_f32, int32_t cout_store,
                        int32_t out_stride, void* stream);
 /* Implementation switch for A/B measurements: 1 = register-staged double-buffered kernel,
- * 2 (default) = LDS-DMA (global_load_lds) kernel.  The 7x7 stem always uses 1.  Process-global. */
+ * 2 (default) = LDS-DMA (global_load_lds) kernels incl. the kw-reuse 3x3 kernel, 3 = LDS-DMA kernels with the
+ * generic (per-tap) 3x3.  The 7x7 stem always uses 1.  Process-global. */
 int pe_set_conv_impl(int32_t impl);
+/* Measurement aid (results become WRONG): 0 = normal, 1 = skip the LDS-DMA loads, 2 = skip the MFMAs of the
+ * kw-reuse 3x3 kernel.  Used by scripts/ablate_conv.py only. */
+int pe_set_conv_ablation(int32_t mode);
 
 /* ---------------------------------------------------------------------------------------------
  * Front-end layout kernels.
@@ -131,6 +135,11 @@ int pe_preprocess_pack(const void* src, int32_t src_kind, int32_t src_h, int32_t
                        int32_t ch0, int32_t nch, int32_t flip_rgb, int32_t dst_h, int32_t dst_w,
                        int32_t pad_h, int32_t pad_w, const float* mean_host, const float* std_host,
                        void* dst, void* stream);
+/* Same for num_images equally sized images stored back to back (src [N,...], dst [N,pad_h,pad_w,4]): one launch. */
+int pe_preprocess_pack_batch(const void* src, int32_t num_images, int32_t src_kind, int32_t src_h, int32_t src_w,
+                             int32_t src_c, int32_t ch0, int32_t nch, int32_t flip_rgb, int32_t dst_h, int32_t dst_w,
+                             int32_t pad_h, int32_t pad_w, const float* mean_host, const float* std_host, void* dst,
+                             void* stream);
 int pe_maxpool3x3s2_nhwc(const void* in, void* out, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
 int pe_subsample2_nhwc(const void* in, void* out, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
 

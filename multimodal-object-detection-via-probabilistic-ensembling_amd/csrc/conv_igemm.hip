@@ -286,15 +286,23 @@ namespace pe {
 int conv2_dispatch(const void* in, const void* wgt, const float* bias, const void* res, void* out, int N, int H, int W,
                    int Cin, int Cout, int Ho, int Wo, int K, int M, int mode3x3, int stride, int relu, int res_mode,
                    int resH, int resW, int out_f32, int cout_store, int out_stride, hipStream_t st);
+extern int g_conv3x3_reuse;
+extern int g_conv_ablate;
 static int g_conv_impl = 2;  // 1: register-staged double-buffer kernel (this file); 2: LDS-DMA kernel (conv_igemm2.hip)
 }  // namespace pe
 
 extern "C" int pe_set_conv_impl(int impl) {
-    if (impl != 1 && impl != 2) {
-        pe::set_error("pe_set_conv_impl: impl %d not in {1,2}", impl);
+    if (impl < 1 || impl > 3) {
+        pe::set_error("pe_set_conv_impl: impl %d not in {1,2,3}", impl);
         return PE_ERR_INVALID_ARG;
     }
-    pe::g_conv_impl = impl;
+    pe::g_conv_impl = impl == 1 ? 1 : 2;
+    pe::g_conv3x3_reuse = impl == 2 ? 1 : 0;
+    return PE_OK;
+}
+
+extern "C" int pe_set_conv_ablation(int mode) {
+    pe::g_conv_ablate = mode;
     return PE_OK;
 }
 

@@ -45,10 +45,106 @@ struct Conv2Args {
     int resH, resW;
     int out_f32, cout_store, out_stride;
     int tiles_m, tiles_n;
+    int ablate;  // measurement only (pe_set_conv_ablation): 1 = skip the LDS-DMA loads, 2 = skip the MFMAs
 };
 
 typedef const void __attribute__((address_space(1)))* gptr_t;
 typedef void __attribute__((address_space(3)))* lptr_t;
+
+// ---- shared epilogue: passes of 64 rows through LDS (fp32), vectorised bias / residual / ReLU / store ----
+// Wave (wm, wn) owns rows [64*wm, 64*wm+64) x columns [WN*wn, WN*wn+WN) of the block tile.
+template <int BM, int BN, int THREADS = 256>
+__device__ __forceinline__ void epilogue(const Conv2Args& a, float16v (&acc)[2][BN / 64], unsigned char* smem, int m0,
+                                         int n0, int tid, int lane, int wm, int wn) {
+    constexpr int WN = BN / 2;
+    constexpr int TM = 2, TN = BN / 64;
+    constexpr int EP_ROWS = 64;
+    constexpr int PASSES = BM / 64;
+    constexpr int EP_ROW = BN + 4;
+    constexpr int VEC_PER_ROW = BN / 8;
+    constexpr int NV = EP_ROWS * VEC_PER_ROW / THREADS;
+    static_assert(NV >= 1, "epilogue needs at least one vector per thread");
+    float* ep = reinterpret_cast<float*>(smem);
+    const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int pass = 0; pass < PASSES; ++pass) {
+        half8 rres[NV];
+        if (a.res_mode) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int v = tid + i * THREADS;
+                const int r = v / VEC_PER_ROW, c8 = (v - r * VEC_PER_ROW) * 8;
+                const int m = m0 + pass * EP_ROWS + r, c = n0 + c8;
+                rres[i] = zero8;
+                if (m < a.M && c < a.cout_store) {
+                    size_t ro;
+                    if (a.res_mode == 1) {
+                        ro = (size_t)m * a.Cout + c;
+                    } else {
+                        const int ow = m % a.Wo, t = m / a.Wo;
+                        const int oh = t % a.Ho, n = t / a.Ho;
+                        ro = (((size_t)n * a.resH + (oh >> 1)) * a.resW + (ow >> 1)) * a.Cout + c;
+                    }
+                    rres[i] = *reinterpret_cast<const half8*>(a.res + ro);
+                }
+            }
+        }
+        if (wm == pass) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int r = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                        const int c = wn * WN + j * 32 + (lane & 31);
+                        ep[r * EP_ROW + c] = acc[i][j][e];
+                    }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int v = tid + i * THREADS;
+            const int r = v / VEC_PER_ROW, c8 = (v - r * VEC_PER_ROW) * 8;
+            const int m = m0 + pass * EP_ROWS + r, c = n0 + c8;
+            if (m >= a.M || c >= a.cout_store) continue;
+            const float4v x0 = *reinterpret_cast<const float4v*>(ep + r * EP_ROW + c8);
+            const float4v x1 = *reinterpret_cast<const float4v*>(ep + r * EP_ROW + c8 + 4);
+            float x[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+            if (a.bias) {
+                if (c + 8 <= a.Cout) {
+                    const float4v b0 = *reinterpret_cast<const float4v*>(a.bias + c);
+                    const float4v b1 = *reinterpret_cast<const float4v*>(a.bias + c + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { x[e] += b0[e]; x[e + 4] += b1[e]; }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) x[e] += (c + e < a.Cout) ? a.bias[c + e] : 0.f;
+                }
+            }
+            if (a.res_mode) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] += (float)rres[i][e];
+            }
+            if (a.relu) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] = fmaxf(x[e], 0.f);
+            }
+            if (a.out_f32) {
+                float* o = reinterpret_cast<float*>(a.out) + (size_t)m * a.out_stride + c;
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (c + e < a.cout_store) o[e] = x[e];
+            } else {
+                half8 h;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) h[e] = (_Float16)x[e];
+                *reinterpret_cast<half8*>(reinterpret_cast<_Float16*>(a.out) + (size_t)m * a.out_stride + c) = h;
+            }
+        }
+        __syncthreads();
+    }
+}
 
 template <int BM, int BN, int MODE>
 __global__ __launch_bounds__(256, 3) void conv_igemm2_kernel(Conv2Args a) {
@@ -157,89 +253,163 @@ __global__ __launch_bounds__(256, 3) void conv_igemm2_kernel(Conv2Args a) {
         __syncthreads();  // every wave is done reading before the next K-step's DMA lands
     }
 
-    // ---- epilogue: two passes of BM/2 rows through LDS (fp32), vectorised bias / residual / ReLU / store ----
-    constexpr int VEC_PER_ROW = BN / 8;
-    constexpr int NV = EP_ROWS * VEC_PER_ROW / 256;
-    float* ep = reinterpret_cast<float*>(smem);
-    const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-        half8 rres[NV];
-        if (a.res_mode) {
-#pragma unroll
-            for (int i = 0; i < NV; ++i) {
-                const int v = tid + i * 256;
-                const int r = v / VEC_PER_ROW, c8 = (v - r * VEC_PER_ROW) * 8;
-                const int m = m0 + pass * EP_ROWS + r, c = n0 + c8;
-                rres[i] = zero8;
-                if (m < a.M && c < a.cout_store) {
-                    size_t ro;
-                    if (a.res_mode == 1) {
-                        ro = (size_t)m * a.Cout + c;
-                    } else {
-                        const int ow = m % a.Wo, t = m / a.Wo;
-                        const int oh = t % a.Ho, n = t / a.Ho;
-                        ro = (((size_t)n * a.resH + (oh >> 1)) * a.resW + (ow >> 1)) * a.Cout + c;
-                    }
-                    rres[i] = *reinterpret_cast<const half8*>(a.res + ro);
-                }
-            }
-        }
-        if (wm == pass) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int r = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                        const int c = wn * WN + j * 32 + (lane & 31);
-                        ep[r * EP_ROW + c] = acc[i][j][e];
-                    }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int v = tid + i * 256;
-            const int r = v / VEC_PER_ROW, c8 = (v - r * VEC_PER_ROW) * 8;
-            const int m = m0 + pass * EP_ROWS + r, c = n0 + c8;
-            if (m >= a.M || c >= a.cout_store) continue;
-            const float4v x0 = *reinterpret_cast<const float4v*>(ep + r * EP_ROW + c8);
-            const float4v x1 = *reinterpret_cast<const float4v*>(ep + r * EP_ROW + c8 + 4);
-            float x[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
-            if (a.bias) {
-                if (c + 8 <= a.Cout) {
-                    const float4v b0 = *reinterpret_cast<const float4v*>(a.bias + c);
-                    const float4v b1 = *reinterpret_cast<const float4v*>(a.bias + c + 4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { x[e] += b0[e]; x[e + 4] += b1[e]; }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) x[e] += (c + e < a.Cout) ? a.bias[c + e] : 0.f;
-                }
-            }
-            if (a.res_mode) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) x[e] += (float)rres[i][e];
-            }
-            if (a.relu) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) x[e] = fmaxf(x[e], 0.f);
-            }
-            if (a.out_f32) {
-                float* o = reinterpret_cast<float*>(a.out) + (size_t)m * a.out_stride + c;
-#pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    if (c + e < a.cout_store) o[e] = x[e];
-            } else {
-                half8 h;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) h[e] = (_Float16)x[e];
-                *reinterpret_cast<half8*>(reinterpret_cast<_Float16*>(a.out) + (size_t)m * a.out_stride + c) = h;
-            }
-        }
-        __syncthreads();
+    epilogue<BM, BN>(a, acc, smem, m0, n0, tid, lane, wm, wn);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// 3x3 (stride 1, pad 1) with kw-tap reuse of the A slab.
+// The generic kernel above moves one 16 KiB A tile per (tap, 64-channel chunk): every input pixel crosses
+// L2 -> LDS nine times.  For a fixed kernel row kh the three kw taps read the SAME pixels shifted by one
+// position, so here the block loads ONE slab of BM + 2 consecutive (linear) input pixels per (kh, chunk)
+// and runs the three kw taps from LDS rows i, i+1, i+2 - only the 16 KiB weight tile changes per tap.
+// L2 -> LDS bytes per 3 taps: 17 + 3*16 = 65 KiB instead of 96 KiB; same LDS footprint (33 KiB).
+// Correctness of the shift across image-row / image boundaries:
+//   * slab row j holds input pixel q = m0 - 1 + j + (kh-1)*W; it is loaded as ZERO when its centre user
+//     (output pixel m0 + j - 1) has oh + kh - 1 outside [0, H) or lies outside [0, M);
+//   * its two other users (kw = 0 / 2) either sit in the same image row (same validity) or are exactly the
+//     cases ow == 0 (kw = 0) / ow == W-1 (kw = 2), which are masked to zero on the A FRAGMENT (per lane).
+template <int BM, int BN, int ABL>
+__global__ __launch_bounds__(BM * 2, BM == 128 ? 3 : 4) void conv3x3r_kernel(Conv2Args a) {
+    constexpr int THREADS = BM * 2, WAVES = BM / 32;   // waves as (BM/64) x 2, each 64 x (BN/2)
+    constexpr int WM = 64, WN = BN / 2;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int SLAB_ROWS = BM + 8;         // BM + 2 rounded up to a multiple of 8
+    constexpr int LAST_GROUP = BM / 8;        // DMA group holding slab rows BM .. BM+7 (wave 0's extra one)
+    constexpr int B_INSTR = BN / 8 / WAVES;
+    constexpr int A_BYTES = SLAB_ROWS * ROW_B;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int nwg = a.tiles_m * a.tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
+    const int tile_n = bid % a.tiles_n, tile_m = bid / a.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lrow = lane >> 3, lp = lane & 7;
+
+    // slab DMA: wave w owns row groups 4w..4w+3, wave 0 also the last group (descriptors are recomputed per slab
+    // - once per three K-steps - instead of living in registers)
+    constexpr int A_INSTR = 5;
+    const _Float16* b_src[B_INSTR];
+#pragma unroll
+    for (int i = 0; i < B_INSTR; ++i) {
+        const int r = (wave * B_INSTR + i) * 8 + lrow;
+        const int n = n0 + r;
+        b_src[i] = (n < a.Cout) ? a.wgt + (size_t)n * a.K + (lp ^ ((r >> 1) & 7)) * 8 : nullptr;
+    }
+    const _Float16* zero = reinterpret_cast<const _Float16*>(g_zero_page);
+
+    // fragment rows and edge masks (per lane, per M sub-tile)
+    const int frow = lane & 31, fkh = lane >> 5;
+    bool not_left[TM], not_right[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wm * WM + i * 32 + frow;
+        const int ow = (m < a.M ? m : 0) % a.Wo;
+        not_left[i] = ow != 0;
+        not_right[i] = ow != a.Wo - 1;
+    }
+    const unsigned char* lb = smem + A_BYTES + (wn * WN + frow) * ROW_B;
+    const int fswb = (frow >> 1) & 7;
+
+    float16v acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+    const int chunks = a.Cin / BK;
+    for (int kh = 0; kh < 3; ++kh) {
+        for (int cc = 0; cc < chunks; ++cc) {
+            const int c0 = cc * BK;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                if (kw == 0 && ABL != 1) {
+                    // ---- A slab for (kh, chunk): rows m0-1 .. m0+128 shifted by (kh-1) image rows ----
+#pragma unroll
+                    for (int i = 0; i < A_INSTR; ++i) {
+                        if (i == 4 && wave != 0) continue;  // wave-uniform
+                        const int g = i < 4 ? wave * 4 + i : LAST_GROUP;
+                        const int j = g * 8 + lrow;           // slab row
+                        const int m = m0 + j - 1;             // its centre user
+                        bool ok = m >= 0 && m < a.M && j < BM + 2;
+                        const int mm = ok ? m : 0;
+                        const int ih = (mm / a.Wo) % a.Ho + kh - 1;
+                        ok = ok && (unsigned)ih < (unsigned)a.H;
+                        const _Float16* p = ok ? a.in + (size_t)(mm + (kh - 1) * a.W) * a.Cin + c0 + (lp ^ ((j >> 1) & 7)) * 8 : zero;
+                        __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(smem + g * 1024), 16, 0, 0);
+                    }
+                }
+                // ---- weight tile of tap (kh, kw) ----
+                const int k0 = (kh * 3 + kw) * a.Cin + c0;
+#pragma unroll
+                for (int i = 0; i < (ABL == 1 ? 0 : B_INSTR); ++i) {
+                    const _Float16* p = b_src[i] ? b_src[i] + k0 : zero;
+                    __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(smem + A_BYTES + (wave * B_INSTR + i) * 1024), 16, 0, 0);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                // slab row of output row r for this tap = r + kw
+                const int arow0 = wm * WM + frow + kw;
+#pragma unroll
+                for (int ks = 0; ks < BK / 16; ++ks) {
+                    half8 af[TM], bf[TN];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        const int r = arow0 + i * 32;
+                        const int ch = ((ks * 2 + fkh) ^ ((r >> 1) & 7)) << 4;
+                        af[i] = *reinterpret_cast<const half8*>(smem + r * ROW_B + ch);
+                        if (kw == 0) af[i] = not_left[i] ? af[i] : zero8;
+                        if (kw == 2) af[i] = not_right[i] ? af[i] : zero8;
+                    }
+                    const int chb = ((ks * 2 + fkh) ^ fswb) << 4;
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const half8*>(lb + j * 32 * ROW_B + chb);
+                    if (ABL == 2) {
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+#pragma unroll
+                            for (int j = 0; j < TN; ++j) acc[i][j][0] += (float)af[i][0] + (float)bf[j][0];
+                        continue;
+                    }
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                }
+                __syncthreads();
+            }
+        }
+    }
+    epilogue<BM, BN, THREADS>(a, acc, smem, m0, n0, tid, lane, wm, wn);
+}
+
+template <int BM, int BN>
+int launch3x3r(const Conv2Args& a0, hipStream_t st) {
+    Conv2Args a = a0;
+    a.tiles_m = pe::ceil_div(a.M, BM);
+    a.tiles_n = pe::ceil_div(a.Cout, BN);
+    constexpr size_t stage = (size_t)(BM + 8 + BN) * ROW_B;
+    constexpr size_t epi = (size_t)64 * (BN + 4) * 4;
+    constexpr size_t lds = stage > epi ? stage : epi;
+    const dim3 grid(a.tiles_m * a.tiles_n), block(BM * 2);
+    if (a.ablate == 1)
+        hipLaunchKernelGGL((conv3x3r_kernel<BM, BN, 1>), grid, block, lds, st, a);
+    else if (a.ablate == 2)
+        hipLaunchKernelGGL((conv3x3r_kernel<BM, BN, 2>), grid, block, lds, st, a);
+    else
+        hipLaunchKernelGGL((conv3x3r_kernel<BM, BN, 0>), grid, block, lds, st, a);
+    PE_CHECK_LAUNCH("pe_conv2d_nhwc_f16(3x3 row-reuse)");
+    return PE_OK;
 }
 
 template <int BM, int BN, int MODE>
@@ -258,6 +428,9 @@ int launch2(const Conv2Args& a0, hipStream_t st) {
 }  // namespace
 
 namespace pe {
+int g_conv_ablate = 0;
+int g_conv_tile256 = 1;
+int g_conv3x3_reuse = 1;  // pe_set_conv_impl(3) turns the kw-reuse 3x3 kernel off (A/B measurements)
 // called from pe_conv2d_nhwc_f16 (conv_igemm.hip) for the 1x1 / 3x3 cases
 int conv2_dispatch(const void* in, const void* wgt, const float* bias, const void* res, void* out, int N, int H, int W,
                    int Cin, int Cout, int Ho, int Wo, int K, int M, int mode3x3, int stride, int relu, int res_mode,
@@ -266,8 +439,14 @@ int conv2_dispatch(const void* in, const void* wgt, const float* bias, const voi
     a.in = (const _Float16*)in; a.wgt = (const _Float16*)wgt; a.bias = bias; a.res = (const _Float16*)res; a.out = out;
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout; a.stride = stride; a.M = M; a.K = K;
     a.relu = relu; a.res_mode = res_mode; a.resH = resH; a.resW = resW; a.out_f32 = out_f32;
-    a.cout_store = cout_store; a.out_stride = out_stride;
+    a.cout_store = cout_store; a.out_stride = out_stride; a.ablate = g_conv_ablate;
     const bool narrow = Cout <= 64;
+    if (mode3x3 && g_conv3x3_reuse) {
+        if (narrow) return launch3x3r<128, 64>(a, st);
+        // 256-row tiles (8 waves) halve the weight-tile traffic per flop; keep 128 when the grid would not fill the chip
+        const bool big = g_conv_tile256 && (long long)pe::ceil_div(M, 256) * pe::ceil_div(Cout, 128) >= 512;
+        return big ? launch3x3r<256, 128>(a, st) : launch3x3r<128, 128>(a, st);
+    }
     if (mode3x3) return narrow ? launch2<128, 64, MODE_3X3>(a, st) : launch2<128, 128, MODE_3X3>(a, st);
     return narrow ? launch2<128, 64, MODE_1X1>(a, st) : launch2<128, 128, MODE_1X1>(a, st);
 }

@@ -23,6 +23,7 @@ struct PackArgs {
     int pad_h, pad_w;  // padded size (multiple of 32)
     float mean[4], inv_std[4];
     _Float16* dst;  // [pad_h, pad_w, 4]
+    size_t src_image_bytes;  // batched form: image z starts at src + z * src_image_bytes
 };
 
 __device__ __forceinline__ float src_at(const PackArgs& a, int y, int x, int c) {
@@ -32,6 +33,8 @@ __device__ __forceinline__ float src_at(const PackArgs& a, int y, int x, int c) 
 }
 
 __global__ void preprocess_pack_kernel(PackArgs a) {
+    a.src = reinterpret_cast<const unsigned char*>(a.src) + (size_t)blockIdx.z * a.src_image_bytes;
+    a.dst += (size_t)blockIdx.z * a.pad_h * a.pad_w * 4;
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y;
     if (x >= a.pad_w) return;
@@ -111,10 +114,10 @@ __global__ void subsample2_kernel(const _Float16* in, _Float16* out, int N, int 
 }
 }  // namespace
 
-extern "C" int pe_preprocess_pack(const void* src, int32_t src_kind, int32_t src_h, int32_t src_w, int32_t src_c,
-                                  int32_t ch0, int32_t nch, int32_t flip_rgb, int32_t dst_h, int32_t dst_w,
-                                  int32_t pad_h, int32_t pad_w, const float* mean_host, const float* std_host,
-                                  void* dst, void* stream) {
+static int preprocess_launch(const void* src, int32_t num_images, int32_t src_kind, int32_t src_h, int32_t src_w,
+                             int32_t src_c, int32_t ch0, int32_t nch, int32_t flip_rgb, int32_t dst_h, int32_t dst_w,
+                             int32_t pad_h, int32_t pad_w, const float* mean_host, const float* std_host, void* dst,
+                             void* stream) {
     PE_CHECK_ARG(src && dst && mean_host && std_host, "pe_preprocess_pack: null pointer");
     PE_CHECK_ARG(src_kind >= 0 && src_kind <= 2, "pe_preprocess_pack: src_kind %d", src_kind);
     PE_CHECK_ARG(nch >= 1 && nch <= 4 && ch0 >= 0 && ch0 + nch <= src_c, "pe_preprocess_pack: channel window [%d,%d) of %d",
@@ -123,13 +126,32 @@ extern "C" int pe_preprocess_pack(const void* src, int32_t src_kind, int32_t src
     PackArgs a{};
     a.src = src; a.src_kind = src_kind; a.src_h = src_h; a.src_w = src_w; a.src_c = src_c; a.ch0 = ch0; a.nch = nch;
     a.flip_rgb = flip_rgb; a.dst_h = dst_h; a.dst_w = dst_w; a.pad_h = pad_h; a.pad_w = pad_w; a.dst = (_Float16*)dst;
+    a.src_image_bytes = (size_t)src_h * src_w * src_c * (src_kind == 0 ? 1 : 4);
+    PE_CHECK_ARG(num_images >= 1 && num_images <= 65535, "pe_preprocess_pack: num_images %d", num_images);
     for (int c = 0; c < 4; ++c) {
         a.mean[c] = c < nch ? mean_host[c] : 0.f;
         a.inv_std[c] = c < nch ? 1.f / std_host[c] : 0.f;
     }
-    hipLaunchKernelGGL(preprocess_pack_kernel, dim3(pe::ceil_div(pad_w, 256), pad_h), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(preprocess_pack_kernel, dim3(pe::ceil_div(pad_w, 256), pad_h, num_images), dim3(256), 0,
+                       (hipStream_t)stream, a);
     PE_CHECK_LAUNCH("pe_preprocess_pack");
     return PE_OK;
+}
+
+extern "C" int pe_preprocess_pack(const void* src, int32_t src_kind, int32_t src_h, int32_t src_w, int32_t src_c,
+                                  int32_t ch0, int32_t nch, int32_t flip_rgb, int32_t dst_h, int32_t dst_w,
+                                  int32_t pad_h, int32_t pad_w, const float* mean_host, const float* std_host,
+                                  void* dst, void* stream) {
+    return preprocess_launch(src, 1, src_kind, src_h, src_w, src_c, ch0, nch, flip_rgb, dst_h, dst_w, pad_h, pad_w,
+                             mean_host, std_host, dst, stream);
+}
+
+extern "C" int pe_preprocess_pack_batch(const void* src, int32_t num_images, int32_t src_kind, int32_t src_h,
+                                        int32_t src_w, int32_t src_c, int32_t ch0, int32_t nch, int32_t flip_rgb,
+                                        int32_t dst_h, int32_t dst_w, int32_t pad_h, int32_t pad_w,
+                                        const float* mean_host, const float* std_host, void* dst, void* stream) {
+    return preprocess_launch(src, num_images, src_kind, src_h, src_w, src_c, ch0, nch, flip_rgb, dst_h, dst_w, pad_h,
+                             pad_w, mean_host, std_host, dst, stream);
 }
 
 extern "C" int pe_maxpool3x3s2_nhwc(const void* in, void* out, int32_t N, int32_t H, int32_t W, int32_t C, void* stream) {

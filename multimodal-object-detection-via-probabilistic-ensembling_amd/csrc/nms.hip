@@ -139,32 +139,52 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(NmsArgs a) {
     a.mask[((size_t)b * a.n_max + r) * a.words + blockIdx.x] = bits;
 }
 
-// one wavefront per image
+// One wavefront per image, 64 sorted boxes per step ("pull" form):
+//   1. the removed word of chunk c = OR over ALL boxes kept so far of their mask word c: the kept list lives
+//      in LDS, lanes stride over it with independent loads (one memory latency per chunk), then a wave OR;
+//   2. lane l fetches the DIAGONAL word of row 64c+l and the chunk is resolved in registers with scalar
+//      readlanes (64 short steps, no memory);
+//   3. survivors are appended to the kept list / output in order; early exit at max_out.
 __global__ __launch_bounds__(64) void nms_scan_kernel(NmsArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned short* kept_pos = reinterpret_cast<unsigned short*>(smem);  // sorted positions of kept boxes
     const int b = blockIdx.x, lane = threadIdx.x;
     const int nv = a.nvalid[b];
     const int words = (nv + 63) / 64;
-    constexpr int MAXW = 4;  // words per lane: supports up to 64*64*4 = 16384 boxes
-    unsigned long long removed[MAXW] = {0, 0, 0, 0};
     int kept = 0;
     const unsigned long long* mk = a.mask + (size_t)b * a.n_max * a.words;
-    for (int i = 0; i < nv && kept < a.max_out; ++i) {
-        const int w = i >> 6;
-        // owner lane of word w is (w & 63), slot (w >> 6)
-        unsigned long long word = 0;
-#pragma unroll
-        for (int s = 0; s < MAXW; ++s)
-            if ((w >> 6) == s) word = removed[s];
-        word = __shfl(word, w & 63);
-        if ((word >> (i & 63)) & 1ull) continue;
-        if (lane == 0) a.out_keep[(size_t)b * a.max_out + kept] = a.sidx[(size_t)b * a.n_max + i];
-        ++kept;
-        // OR row i into the removed set; columns < i's tile were never written -> start at tile w
-#pragma unroll
-        for (int s = 0; s < MAXW; ++s) {
-            const int ww = s * 64 + lane;
-            if (ww >= w && ww < words) removed[s] |= mk[(size_t)i * a.words + ww];
+    for (int c = 0; c < words && kept < a.max_out; ++c) {
+        const int i0 = c * 64;
+        // ---- 1. pull: who among the kept boxes suppresses members of this chunk ----
+        unsigned long long rem = 0;
+        for (int k = lane; k < kept; k += 64) {
+            const int p = kept_pos[k];
+            if ((p >> 6) < c) rem |= mk[(size_t)p * a.words + c];  // rows of earlier chunks only (same chunk: step 2)
         }
+        for (int o = 32; o > 0; o >>= 1) rem |= __shfl_xor(rem, o);
+        // ---- 2. resolve the chunk in registers ----
+        const int row = i0 + lane;
+        const unsigned long long diag = row < nv ? mk[(size_t)row * a.words + c] : 0ull;
+        const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
+        const int nb = min(64, nv - i0);
+        unsigned long long keepmask = 0;
+        int kept_here = 0;
+        for (int bit = 0; bit < nb; ++bit) {
+            if ((rem >> bit) & 1ull) continue;          // wave-uniform
+            if (kept + kept_here >= a.max_out) break;
+            keepmask |= 1ull << bit;
+            ++kept_here;
+            const unsigned lo = __builtin_amdgcn_readlane(dlo, bit), hi = __builtin_amdgcn_readlane(dhi, bit);
+            rem |= ((unsigned long long)hi << 32) | lo;
+        }
+        // ---- 3. emit the survivors in order ----
+        if ((keepmask >> lane) & 1ull) {
+            const int slot = kept + __popcll(keepmask & pe::lanemask_lt());
+            kept_pos[slot] = (unsigned short)row;
+            a.out_keep[(size_t)b * a.max_out + slot] = a.sidx[(size_t)b * a.n_max + row];
+        }
+        kept += kept_here;
+        __syncthreads();
     }
     if (lane == 0) a.out_counts[b] = kept;
 }
@@ -220,7 +240,7 @@ extern "C" int pe_nms_batched(const float* boxes, const float* scores, const int
     PE_CHECK_LAUNCH("pe_nms_batched(sort)");
     hipLaunchKernelGGL(nms_mask_kernel, dim3(a.words, a.words, B), dim3(64), 0, st, a);
     PE_CHECK_LAUNCH("pe_nms_batched(mask)");
-    hipLaunchKernelGGL(nms_scan_kernel, dim3(B), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(B), dim3(64), (size_t)std::min(max_out, n_max) * 2 + 16, st, a);
     PE_CHECK_LAUNCH("pe_nms_batched(scan)");
     return PE_OK;
 }

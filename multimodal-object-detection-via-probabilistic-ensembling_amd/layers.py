@@ -196,3 +196,18 @@ def preprocess_pack(src, dst, *, src_kind, ch0, nch, flip_rgb, dst_hw, mean, std
     st = _lib.lib().pe_preprocess_pack(_lib.ptr(src), src_kind, h, w, c, ch0, nch, int(flip_rgb), dst_hw[0], dst_hw[1],
                                        dst.shape[0], dst.shape[1], m, s, _lib.ptr(dst), _lib.stream())
     _lib.check(st, "pe_preprocess_pack")
+
+
+def preprocess_pack_batch(src, dst, *, src_kind, ch0, nch, flip_rgb, dst_hw, mean, std):
+    """src: [N,H,W,C] (u8 / f32) or [N,C,H,W] f32 batch of equally sized images; dst: [N,pad_h,pad_w,4] fp16."""
+    _lib.require_cuda(src, dst)
+    n = src.shape[0]
+    if src_kind == 2:
+        c, h, w = src.shape[1:]
+    else:
+        h, w, c = src.shape[1:]
+    m = (ctypes.c_float * 4)(*(list(mean) + [0.0] * (4 - len(mean))))
+    s = (ctypes.c_float * 4)(*(list(std) + [1.0] * (4 - len(std))))
+    st = _lib.lib().pe_preprocess_pack_batch(_lib.ptr(src), n, src_kind, h, w, c, ch0, nch, int(flip_rgb), dst_hw[0], dst_hw[1],
+                                             dst.shape[1], dst.shape[2], m, s, _lib.ptr(dst), _lib.stream())
+    _lib.check(st, "pe_preprocess_pack_batch")

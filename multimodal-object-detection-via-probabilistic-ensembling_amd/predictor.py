@@ -69,7 +69,7 @@ class DefaultPredictor:
         h, w = images[0].shape[:2]
         for im in images:
             assert im.shape[:2] == (h, w), "predict_batch expects equally sized frames"
-        det = self.model.forward_batch([self._to_device(im) for im in images], out_sizes=[(h, w)] * len(images),
+        det = self.model.forward_batch(torch.stack([self._to_device(im) for im in images]), out_sizes=[(h, w)] * len(images),
                                        resize_to=resize_shortest_edge_shape(h, w, self.min_size, self.max_size))
         return self.model.to_instances(det)
 

@@ -131,6 +131,8 @@ class GeneralizedRCNN:
         Returns NHWC4 fp16 batch(es) and [(h, w)] of the resized, unpadded images."""
         cfg = self.cfg
         C = cfg.in_channels
+        if isinstance(images, torch.Tensor):  # one [N,H,W,C] (or [N,C,H,W] f32) batch of equally sized frames
+            return self._preprocess_batch(images, resize_to)
         sizes, kinds = [], []
         for im in images:
             chw = im.dim() == 3 and im.shape[0] == C and im.dtype == torch.float32 and im.shape[2] != C
@@ -153,6 +155,27 @@ class GeneralizedRCNN:
                                   dst_hw=sizes[i], mean=mean[ch0:ch0 + nch], std=std[ch0:ch0 + nch])
             batches.append(x)
         return batches, sizes
+
+    def _preprocess_batch(self, images, resize_to):
+        cfg = self.cfg
+        C = cfg.in_channels
+        N = images.shape[0]
+        chw = images.dtype == torch.float32 and images.shape[1] == C and images.shape[3] != C
+        kind = 2 if chw else (0 if images.dtype == torch.uint8 else 1)
+        h, w = (images.shape[2], images.shape[3]) if chw else (images.shape[1], images.shape[2])
+        size = tuple(resize_to) if (resize_to is not None and not chw) else (h, w)
+        d = cfg.size_divisibility
+        Hp, Wp = (size[0] + d - 1) // d * d, (size[1] + d - 1) // d * d
+        mean = list(cfg.pixel_mean)
+        std = list(cfg.pixel_std) + [cfg.pixel_std[-1]] * (C - len(cfg.pixel_std))
+        assert len(mean) == C, f"PIXEL_MEAN needs {C} entries for INPUT.FORMAT {cfg.input_format}"
+        batches = []
+        for ch0, nch in ([(0, min(C, 4))] if C <= 4 else [(0, 3), (3, 3)]):
+            x = torch.empty((N, Hp, Wp, 4), dtype=torch.float16, device=self.device)
+            L.preprocess_pack_batch(images.contiguous(), x, src_kind=kind, ch0=ch0, nch=nch, flip_rgb=False, dst_hw=size,
+                                    mean=mean[ch0:ch0 + nch], std=std[ch0:ch0 + nch])
+            batches.append(x)
+        return batches, [size] * N
 
     def _rpn(self, feats, sizes_dev, N):
         cfg = self.cfg
@@ -238,7 +261,7 @@ class GeneralizedRCNN:
         out_sizes: list of (height, width) per image for the final rescale (default: resized size).
         Returns a dict of padded device tensors: boxes [N,D,4], scores, classes, class_logits,
         prob_score, vars, counts [N]."""
-        N = len(images)
+        N = images.shape[0] if isinstance(images, torch.Tensor) else len(images)
         batches, sizes = self._preprocess(images, resize_to)
         dev = self.device
         sizes_dev = torch.tensor(sizes, dtype=torch.int32, device=dev)

@@ -1,0 +1,46 @@
+"""Ablation of the dominant kernel (3x3, 256->256 at 50x64, batch 32 = res4 conv2): how much of its time
+is LDS-DMA (global_load_lds) wait vs MFMA + fragment reads.  Usage (GPU box): python scripts/ablate_conv.py"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import proben_amd  # noqa: E402
+from proben_amd import _lib, layers as L  # noqa: E402
+
+
+def timeit(fn, reps=20):
+    for _ in range(3):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def main():
+    lib = _lib.lib()
+    shapes = [(32, 50, 64, 256, 256, 3), (32, 200, 256, 256, 256, 3), (32, 50, 64, 1024, 256, 1), (32, 50, 64, 256, 1024, 1)]
+    for (N, H, W, Cin, Cout, k) in shapes:
+        x = torch.randn(N, H, W, Cin, device="cuda").half()
+        w = (torch.randn(Cout, k, k, Cin, device="cuda") / (Cin * k * k) ** 0.5).half()
+        b = torch.randn(Cout, device="cuda")
+        out = torch.empty(N, H, W, Cout, device="cuda", dtype=torch.float16)
+        fl = 2.0 * N * H * W * Cout * k * k * Cin
+        row = []
+        for impl, abl in [(1, 0), (3, 0), (2, 0), (2, 1), (2, 2)]:
+            lib.pe_set_conv_impl(impl)
+            lib.pe_set_conv_ablation(abl)
+            ms = timeit(lambda: L.conv2d_nhwc(x, w, b, kernel=k, relu=True, out=out))
+            row.append(f"impl{impl}/abl{abl}: {ms:.4f} ms {fl / ms / 1e9:7.1f} TF")
+        lib.pe_set_conv_impl(2)
+        lib.pe_set_conv_ablation(0)
+        print(f"N{N} {H}x{W} {Cin}->{Cout} k{k} | " + " | ".join(row), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -17,19 +17,21 @@ def iou_matrix(a, b):
     return inter / (aa[:, None] + ab[None, :] - inter + 1e-12)
 
 
-def run_pair(depth=50, hw=(480, 608), n_images=2, seed=1):
+def run_pair(depth=50, hw=(480, 608), n_images=2, seed=1, in_channels=3):
     import proben_amd  # noqa: F401
     from oracle import detector as D
     from proben_amd.rcnn import DetectorConfig, GeneralizedRCNN
     from proben_amd.synthetic import synthetic_images, synthetic_state_dict
-    sd = synthetic_state_dict(depth, 3, 3, seed=seed)
-    imgs = synthetic_images(n_images, height=hw[0], width=hw[1], seed=0)
+    sd = synthetic_state_dict(depth, 3, in_channels, seed=seed)
+    imgs = synthetic_images(n_images, height=hw[0], width=hw[1], channels=in_channels, seed=0)
     x = [torch.from_numpy(im).permute(2, 0, 1).float().contiguous() for im in imgs]
     x[-1] = x[-1][:, : hw[0] - 40, : hw[1] - 50].contiguous()  # different size -> padding inside the batch
     outs = [(im.shape[1] // 2, im.shape[2] // 2) for im in x]
     torch.set_num_threads(8)
-    want, inter = D.forward(x, sd, D.DetectorSpec(depth=depth), out_sizes=outs, return_intermediates=True)
-    model = GeneralizedRCNN(DetectorConfig(), sd)
+    want, inter = D.forward(x, sd, D.DetectorSpec(depth=depth, in_channels=in_channels), out_sizes=outs, return_intermediates=True)
+    fmt = {3: "BGR", 4: "BGRT", 6: "BGRTTT"}[in_channels]
+    mean = (103.53, 116.28, 123.675) + (135.438,) * (in_channels - 3)
+    model = GeneralizedRCNN(DetectorConfig(input_format=fmt, pixel_mean=mean, pixel_std=(1.0,) * in_channels), sd)
     det = model.forward_batch([t.cuda() for t in x], out_sizes=outs, keep_intermediates=True)
     torch.cuda.synchronize()
     return want, inter, det, model
@@ -74,6 +76,15 @@ def check_pair(want, inter, det):
 
 def test_r50_forward_matches_oracle():
     want, inter, det, _ = run_pair(50)
+    check_pair(want, inter, det)
+
+
+@pytest.mark.parametrize("in_channels", [4, 6])
+def test_fusion_variants_match_oracle(in_channels):
+    """early fusion (BGRT, 4-channel stem) and middle fusion (BGRTTT: the backbone runs twice -
+    quirk Q1 - and the FPN outputs are concatenated to 512 channels for the RPN / box head)."""
+    want, inter, det, model = run_pair(50, hw=(320, 416), in_channels=in_channels)
+    assert det["_feats"][0].shape[3] == (512 if in_channels == 6 else 256)
     check_pair(want, inter, det)
 
 

@@ -32,6 +32,8 @@ CONV_CASES = [
     (2, 26, 32, 512, 256, 1, 1, False, 2, False),
     (2, 20, 24, 256, 15, 1, 1, False, 0, True),
     (1, 37, 41, 64, 256, 1, 1, False, 0, False),
+    (16, 100, 128, 128, 128, 3, 1, True, 0, False),   # >= 512 tiles of 256 rows: the 8-wave 256x128 3x3 kernel
+    (9, 99, 131, 64, 256, 3, 1, False, 0, False),     # same kernel, ragged M / odd width (edge masks, M tail)
 ]
 
 
