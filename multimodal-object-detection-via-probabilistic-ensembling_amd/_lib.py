@@ -19,6 +19,7 @@ SIGNATURES = {
     "pe_conv2d_nhwc_f16": [c_void_p] * 5 + [c_int] * 14 + [c_void_p],
     "pe_set_conv_impl": [c_int],
     "pe_set_conv_ablation": [c_int],
+    "pe_set_conv_tile256": [c_int],
     "pe_preprocess_pack": [c_void_p] + [c_int] * 11 + [c_void_p] * 4,
     "pe_preprocess_pack_batch": [c_void_p] + [c_int] * 12 + [c_void_p] * 4,
     "pe_maxpool3x3s2_nhwc": [c_void_p] * 2 + [c_int] * 4 + [c_void_p],

@@ -288,6 +288,7 @@ int conv2_dispatch(const void* in, const void* wgt, const float* bias, const voi
                    int resH, int resW, int out_f32, int cout_store, int out_stride, hipStream_t st);
 extern int g_conv3x3_reuse;
 extern int g_conv_ablate;
+extern int g_conv_tile256;
 static int g_conv_impl = 2;  // 1: register-staged double-buffer kernel (this file); 2: LDS-DMA kernel (conv_igemm2.hip)
 }  // namespace pe
 
@@ -298,6 +299,11 @@ extern "C" int pe_set_conv_impl(int impl) {
     }
     pe::g_conv_impl = impl == 1 ? 1 : 2;
     pe::g_conv3x3_reuse = impl == 2 ? 1 : 0;
+    return PE_OK;
+}
+
+extern "C" int pe_set_conv_tile256(int mode) {
+    pe::g_conv_tile256 = mode;
     return PE_OK;
 }
 

@@ -146,15 +146,15 @@ __device__ __forceinline__ void epilogue(const Conv2Args& a, float16v (&acc)[2][
     }
 }
 
-template <int BM, int BN, int MODE>
-__global__ __launch_bounds__(256, 3) void conv_igemm2_kernel(Conv2Args a) {
-    constexpr int WM = BM / 2, WN = BN / 2;
+template <int BM, int BN, int MODE, int STAGES>
+__global__ __launch_bounds__(BM * 2, BM == 128 ? (STAGES == 1 ? 3 : 2) : (STAGES == 1 ? 4 : 2)) void conv_igemm2_kernel(Conv2Args a) {
+    constexpr int THREADS = BM * 2, WAVES = BM / 32;  // waves as (BM/64) x 2, each owning a 64 x (BN/2) sub-tile
+    constexpr int WM = 64, WN = BN / 2;
     constexpr int TM = WM / 32, TN = WN / 32;
-    constexpr int A_INSTR = BM / 32;  // DMA instructions per wave per K-step for A (8 rows each, 4 waves)
-    constexpr int B_INSTR = BN / 32;
+    constexpr int A_INSTR = BM / 8 / WAVES;  // DMA instructions per wave per K-step for A (8 rows each) = 4
+    constexpr int B_INSTR = BN / 8 / WAVES;
     constexpr int A_BYTES = BM * ROW_B;
-    constexpr int EP_ROWS = BM / 2;   // epilogue handles the tile in two passes of BM/2 rows
-    constexpr int EP_ROW = BN + 4;    // floats
+    constexpr int STAGE_BYTES = (BM + BN) * ROW_B;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int nwg = a.tiles_m * a.tiles_n;
@@ -210,9 +210,9 @@ __global__ __launch_bounds__(256, 3) void conv_igemm2_kernel(Conv2Args a) {
     const unsigned char* lb = smem + A_BYTES + (wn * WN + frow) * ROW_B;
 
     const int nk = a.K / BK;
-    for (int kt = 0; kt < nk; ++kt) {
+    // LDS-DMA of K-step kt into LDS stage `st`: global -> LDS, no VGPR round trip
+    auto dma = [&](int kt, int st) {
         const int k0 = kt * BK;
-        // ---- LDS-DMA: global -> LDS, no VGPR round trip ----
         int kh = 0, kw = 0, c0 = k0;
         if (MODE == MODE_3X3) {
             const int tap = k0 / a.Cin;
@@ -220,40 +220,63 @@ __global__ __launch_bounds__(256, 3) void conv_igemm2_kernel(Conv2Args a) {
             kh = tap / 3 - 1;
             kw = tap - (tap / 3) * 3 - 1;
         }
+        unsigned char* base = smem + st * STAGE_BYTES;
 #pragma unroll
         for (int i = 0; i < A_INSTR; ++i) {
             const int ih = a_oh[i] + kh, iw = a_ow[i] + kw;
             bool ok = a_ok[i];
             if (MODE == MODE_3X3) ok = ok && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
             const _Float16* p = ok ? a_base[i] + ((size_t)ih * a.W + iw) * a.Cin + c0 + a_coff[i] : zero;
-            __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(smem + (wave * A_INSTR + i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(base + (wave * A_INSTR + i) * 1024), 16, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < B_INSTR; ++i) {
             const _Float16* p = b_src[i] ? b_src[i] + k0 : zero;
-            __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(smem + A_BYTES + (wave * B_INSTR + i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(base + A_BYTES + (wave * B_INSTR + i) * 1024), 16, 0, 0);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        // ---- fragments + MFMA ----
+    };
+    auto compute = [&](int st) {
+        const unsigned char* pa = la + st * STAGE_BYTES;
+        const unsigned char* pb = lb + st * STAGE_BYTES;
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
             const int ch = ((ks * 2 + fkh) ^ fsw) << 4;
             half8 af[TM], bf[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const half8*>(la + i * 32 * ROW_B + ch);
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const half8*>(pa + i * 32 * ROW_B + ch);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const half8*>(lb + j * 32 * ROW_B + ch);
+            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const half8*>(pb + j * 32 * ROW_B + ch);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
-        __syncthreads();  // every wave is done reading before the next K-step's DMA lands
+    };
+    if (STAGES == 1) {
+        // single stage: DMA wait fully exposed per workgroup; 3-4 co-resident workgroups hide each other's waits
+        for (int kt = 0; kt < nk; ++kt) {
+            dma(kt, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            compute(0);
+            __syncthreads();  // every wave is done reading before the next K-step's DMA lands
+        }
+    } else {
+        // two stages: K-step kt+1 streams into the other stage while K-step kt feeds the MFMAs; one barrier per
+        // K-step (it both publishes stage kt+1 and retires the reads of stage kt)
+        dma(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) dma(kt + 1, (kt + 1) & 1);
+            compute(kt & 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
     }
 
-    epilogue<BM, BN>(a, acc, smem, m0, n0, tid, lane, wm, wn);
+    epilogue<BM, BN, THREADS>(a, acc, smem, m0, n0, tid, lane, wm, wn);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -412,15 +435,23 @@ int launch3x3r(const Conv2Args& a0, hipStream_t st) {
     return PE_OK;
 }
 
-template <int BM, int BN, int MODE>
+template <int BM, int BN, int MODE, int STAGES = 1>
 int launch2(const Conv2Args& a0, hipStream_t st) {
     Conv2Args a = a0;
     a.tiles_m = pe::ceil_div(a.M, BM);
     a.tiles_n = pe::ceil_div(a.Cout, BN);
-    constexpr size_t stage = (size_t)(BM + BN) * ROW_B;
-    constexpr size_t epi = (size_t)(BM / 2) * (BN + 4) * 4;
+    constexpr size_t stage = (size_t)(BM + BN) * ROW_B * STAGES;
+    constexpr size_t epi = (size_t)64 * (BN + 4) * 4;
     constexpr size_t lds = stage > epi ? stage : epi;
-    hipLaunchKernelGGL((conv_igemm2_kernel<BM, BN, MODE>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds, st, a);
+    if (lds > 64 * 1024) {
+        static bool done = false;
+        if (!done) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm2_kernel<BM, BN, MODE, STAGES>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            done = true;
+        }
+    }
+    hipLaunchKernelGGL((conv_igemm2_kernel<BM, BN, MODE, STAGES>), dim3(a.tiles_m * a.tiles_n), dim3(BM * 2), lds, st, a);
     PE_CHECK_LAUNCH("pe_conv2d_nhwc_f16(v2)");
     return PE_OK;
 }
@@ -429,7 +460,7 @@ int launch2(const Conv2Args& a0, hipStream_t st) {
 
 namespace pe {
 int g_conv_ablate = 0;
-int g_conv_tile256 = 1;
+int g_conv_tile256 = 1;  // bit 0: 256-row tiles for big 3x3 launches, bit 1: for big 1x1 launches, bit 2: two-stage 1x1 pipeline
 int g_conv3x3_reuse = 1;  // pe_set_conv_impl(3) turns the kw-reuse 3x3 kernel off (A/B measurements)
 // called from pe_conv2d_nhwc_f16 (conv_igemm.hip) for the 1x1 / 3x3 cases
 int conv2_dispatch(const void* in, const void* wgt, const float* bias, const void* res, void* out, int N, int H, int W,
@@ -444,10 +475,13 @@ int conv2_dispatch(const void* in, const void* wgt, const float* bias, const voi
     if (mode3x3 && g_conv3x3_reuse) {
         if (narrow) return launch3x3r<128, 64>(a, st);
         // 256-row tiles (8 waves) halve the weight-tile traffic per flop; keep 128 when the grid would not fill the chip
-        const bool big = g_conv_tile256 && (long long)pe::ceil_div(M, 256) * pe::ceil_div(Cout, 128) >= 512;
+        const bool big = (g_conv_tile256 & 1) && (long long)pe::ceil_div(M, 256) * pe::ceil_div(Cout, 128) >= 512;
         return big ? launch3x3r<256, 128>(a, st) : launch3x3r<128, 128>(a, st);
     }
     if (mode3x3) return narrow ? launch2<128, 64, MODE_3X3>(a, st) : launch2<128, 128, MODE_3X3>(a, st);
-    return narrow ? launch2<128, 64, MODE_1X1>(a, st) : launch2<128, 128, MODE_1X1>(a, st);
+    if (narrow) return launch2<128, 64, MODE_1X1>(a, st);
+    const bool big1 = (g_conv_tile256 & 2) && (long long)pe::ceil_div(M, 256) * pe::ceil_div(Cout, 128) >= 512;
+    if (g_conv_tile256 & 4) return big1 ? launch2<256, 128, MODE_1X1, 2>(a, st) : launch2<128, 128, MODE_1X1, 2>(a, st);
+    return big1 ? launch2<256, 128, MODE_1X1>(a, st) : launch2<128, 128, MODE_1X1>(a, st);
 }
 }  // namespace pe

@@ -151,15 +151,32 @@ def conv2d_nhwc(x, weight, bias, *, kernel, stride=1, relu=False, residual=None,
                                        int(out_f32), int(cout_store), int(out_stride), _lib.stream())
     _lib.check(st, "pe_conv2d_nhwc_f16")
     if PROFILE is not None:  # bench.py roofline leg: remember the launch so it can be replayed back-to-back
-        kk = {1: "1x1", 3: "3x3", 7: "stem7x7"}[kernel]
-        variant = f"conv_igemm_kernel<128,{64 if Cout <= 64 else 128},{kk}>"
+        variant = conv_variant_name(N * Ho * Wo, Cout, kernel)
         cin_real = 3 if kernel == 7 else Cin
         shape = f"N{N} {H}x{W} Cin{Cin} Cout{Cout} k{kernel} s{stride} res{residual_mode} f32{int(out_f32)}"
+        M = N * Ho * Wo
+        nbytes = (N * H * W * (3 if kernel == 7 else Cin) * 2 + weight.numel() * 2 + M * (cout_store or Cout) * (4 if out_f32 else 2)
+                  + (M * Cout * 2 if residual_mode == 1 else (residual.numel() * 2 if residual_mode == 2 else 0)))
         PROFILE.append({"variant": variant, "shape": shape, "flops": 2.0 * N * Ho * Wo * Cout * kernel * kernel * cin_real,
+                        "bytes": float(nbytes),
                         "args": (x, weight, bias, residual, out, dict(kernel=kernel, stride=stride, relu=relu,
                                  residual_mode=residual_mode, out_f32=out_f32, cout_store=cout_store,
                                  out_stride=out_stride, cout=cout))})
     return out
+
+
+def conv_variant_name(M, Cout, kernel):
+    """Name of the kernel pe_conv2d_nhwc_f16 dispatches to (mirrors conv2_dispatch in csrc/conv_igemm2.hip;
+    matches the rocprofv3 kernel names)."""
+    bn = 64 if Cout <= 64 else 128
+    if kernel == 7:
+        return "conv_igemm_kernel<128, 64, 2>"          # 7x7 stem, register-staged kernel
+    if kernel == 1:
+        return f"conv_igemm2_kernel<128, {bn}, 0>"      # LDS-DMA 1x1 / GEMM
+    if bn == 64:
+        return "conv3x3r_kernel<128, 64, 0>"
+    big = ((M + 255) // 256) * ((Cout + 127) // 128) >= 512
+    return f"conv3x3r_kernel<{256 if big else 128}, 128, 0>"  # kw-reuse 3x3
 
 
 def linear_f16(x, weight, bias, *, relu=False, out_f32=False, cout_store=0, out_stride=0):
