@@ -126,12 +126,28 @@ def roofline_leg(step, layers_path="", reps=10):
              "algorithmic_mbytes_per_launch": round(by / n / 1e6, 1), "flop_per_byte": round(fl / by, 1),
              "tflops": round(tf, 1), "algorithmic_gbs": round(gbs, 1)}
         return d
+    # HBM traffic per launch from the PMC counters: measured by separate `rocprofv3 --pmc` passes (they cannot run
+    # inside this process); profiles/*_pmc_traffic.json holds the last committed measurement per kernel name
+    traffic = {}
+    try:
+        import glob
+        for pth in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json"))):
+            traffic = json.load(open(pth))["kernels"]
+    except Exception:
+        traffic = {}
+
+    def with_traffic(d):
+        key = d["kernel"].replace(" ", "")
+        for k, v in traffic.items():
+            if k.replace(" ", "") == key:
+                d["traffic"] = {"hbm_mbytes_per_launch": v["hbm_mb_per_launch"], "unit": "MB", "source": "rocprofv3 --pmc FETCH_SIZE(x2)+WRITE_SIZE, profiles/"}
+        return d
     dom = max(agg, key=lambda k: agg[k][2])
-    out = describe(dom)
+    out = with_traffic(describe(dom))
     # north_star's MFMA target is quoted on the 3x3 convolutions: always report their kernel as well
     k3 = max((k for k in agg if k.startswith("conv3x3r")), key=lambda k: agg[k][2], default=None)
     if k3 is not None and k3 != dom:
-        out["conv3x3"] = describe(k3)
+        out["conv3x3"] = with_traffic(describe(k3))
     out["all_conv_variants"] = {k: {"launches": v[0], "gflop": round(v[1] / 1e9, 1), "ms": round(v[2] * 1e3, 3),
                                     "tflops": round(v[1] / v[2] / 1e12, 1), "algorithmic_gbs": round(v[3] / v[2] / 1e9, 0)}
                                 for k, v in sorted(agg.items(), key=lambda kv: -kv[1][2])}

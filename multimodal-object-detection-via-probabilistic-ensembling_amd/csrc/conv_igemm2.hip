@@ -435,6 +435,212 @@ int launch3x3r(const Conv2Args& a0, hipStream_t st) {
     return PE_OK;
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Big-tile variant: 256 x 256 x 64 block tile, 8 waves (2 x 4, each 128 x 64 = 4 x 2 MFMA tiles, 128 fp32
+// accumulator registers), TWO LDS stages of 64 KiB: K-step kt+1 streams in by LDS-DMA while K-step kt feeds the
+// MFMAs, one barrier per K-step.  One workgroup per CU (2 waves per SIMD).  Twice the flops per L2->LDS byte of
+// the 128 x 128 kernel (the CU's L2 port, ~64 B/clk, is what the small tile saturates) and 0.75 instead of 1.0
+// fragment reads per MFMA.  Used for launches with Cout % 256 == 0 whose grid fills the chip.
+template <int MODE>
+__global__ __launch_bounds__(512, 2) void conv_big_kernel(Conv2Args a) {
+    constexpr int BM = 256, BN = 256, THREADS = 512;
+    constexpr int WM = 128, WN = 64, TM = 4, TN = 2;
+    constexpr int A_INSTR = 4, B_INSTR = 4;         // 32 row groups of 8 rows over 8 waves, for A and for B
+    constexpr int A_BYTES = BM * ROW_B;
+    constexpr int STAGE_BYTES = (BM + BN) * ROW_B;  // 64 KiB
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int nwg = a.tiles_m * a.tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_n = bid % a.tiles_n, tile_m = bid / a.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int lrow = lane >> 3, lp = lane & 7;
+
+    const _Float16* a_base[A_INSTR];
+    int a_oh[A_INSTR], a_ow[A_INSTR], a_coff[A_INSTR];
+    bool a_ok[A_INSTR];
+#pragma unroll
+    for (int i = 0; i < A_INSTR; ++i) {
+        const int r = (wave * A_INSTR + i) * 8 + lrow;
+        const int m = m0 + r;
+        a_ok[i] = m < a.M;
+        const int mm = a_ok[i] ? m : 0;
+        const int ow = mm % a.Wo, t = mm / a.Wo;
+        const int oh = t % a.Ho, n = t / a.Ho;
+        a_oh[i] = oh * a.stride;
+        a_ow[i] = ow * a.stride;
+        a_base[i] = a.in + (size_t)n * a.H * a.W * a.Cin;
+        a_coff[i] = (lp ^ ((r >> 1) & 7)) * 8;
+    }
+    const _Float16* b_src[B_INSTR];
+#pragma unroll
+    for (int i = 0; i < B_INSTR; ++i) {
+        const int r = (wave * B_INSTR + i) * 8 + lrow;
+        const int n = n0 + r;
+        b_src[i] = (n < a.Cout) ? a.wgt + (size_t)n * a.K + (lp ^ ((r >> 1) & 7)) * 8 : nullptr;
+    }
+    const _Float16* zero = reinterpret_cast<const _Float16*>(g_zero_page);
+
+    float16v acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int frow = lane & 31, fsw = (frow >> 1) & 7, fkh = lane >> 5;
+    const unsigned char* la = smem + (wm * WM + frow) * ROW_B;
+    const unsigned char* lb = smem + A_BYTES + (wn * WN + frow) * ROW_B;
+    const int nk = a.K / BK;
+
+    auto dma = [&](int kt, int st) {
+        const int k0 = kt * BK;
+        int kh = 0, kw = 0, c0 = k0;
+        if (MODE == MODE_3X3) {
+            const int tap = k0 / a.Cin;
+            c0 = k0 - tap * a.Cin;
+            kh = tap / 3 - 1;
+            kw = tap - (tap / 3) * 3 - 1;
+        }
+        unsigned char* base = smem + st * STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < A_INSTR; ++i) {
+            const int ih = a_oh[i] + kh, iw = a_ow[i] + kw;
+            bool ok = a_ok[i];
+            if (MODE == MODE_3X3) ok = ok && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+            const _Float16* p = ok ? a_base[i] + ((size_t)ih * a.W + iw) * a.Cin + c0 + a_coff[i] : zero;
+            __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(base + (wave * A_INSTR + i) * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < B_INSTR; ++i) {
+            const _Float16* p = b_src[i] ? b_src[i] + k0 : zero;
+            __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(base + A_BYTES + (wave * B_INSTR + i) * 1024), 16, 0, 0);
+        }
+    };
+    dma(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) dma(kt + 1, (kt + 1) & 1);
+        const unsigned char* pa = la + (kt & 1) * STAGE_BYTES;
+        const unsigned char* pb = lb + (kt & 1) * STAGE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            const int ch = ((ks * 2 + fkh) ^ fsw) << 4;
+            half8 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const half8*>(pa + i * 32 * ROW_B + ch);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const half8*>(pb + j * 32 * ROW_B + ch);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // ---- epilogue: 4 passes of 64 rows; pass p is owned by the waves with wm == p >> 1 (their row tiles 2*(p&1), +1) ----
+    constexpr int EP_ROW = BN + 4;
+    constexpr int VEC_PER_ROW = BN / 8;
+    constexpr int NV = 64 * VEC_PER_ROW / THREADS;  // 4
+    float* ep = reinterpret_cast<float*>(smem);
+    const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+        half8 rres[NV];
+        if (a.res_mode) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int v = tid + i * THREADS;
+                const int r = v / VEC_PER_ROW, c8 = (v - r * VEC_PER_ROW) * 8;
+                const int m = m0 + pass * 64 + r, c = n0 + c8;
+                rres[i] = zero8;
+                if (m < a.M && c < a.cout_store) {
+                    size_t ro;
+                    if (a.res_mode == 1) {
+                        ro = (size_t)m * a.Cout + c;
+                    } else {
+                        const int ow = m % a.Wo, t = m / a.Wo;
+                        const int oh = t % a.Ho, n = t / a.Ho;
+                        ro = (((size_t)n * a.resH + (oh >> 1)) * a.resW + (ow >> 1)) * a.Cout + c;
+                    }
+                    rres[i] = *reinterpret_cast<const half8*>(a.res + ro);
+                }
+            }
+        }
+        if (wm == (pass >> 1)) {
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int r = ii * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                        const int c = wn * WN + j * 32 + (lane & 31);
+                        ep[r * EP_ROW + c] = acc[2 * (pass & 1) + ii][j][e];
+                    }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int v = tid + i * THREADS;
+            const int r = v / VEC_PER_ROW, c8 = (v - r * VEC_PER_ROW) * 8;
+            const int m = m0 + pass * 64 + r, c = n0 + c8;
+            if (m >= a.M || c >= a.cout_store) continue;
+            const float4v x0 = *reinterpret_cast<const float4v*>(ep + r * EP_ROW + c8);
+            const float4v x1 = *reinterpret_cast<const float4v*>(ep + r * EP_ROW + c8 + 4);
+            float x[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+            if (a.bias) {
+                const float4v b0 = *reinterpret_cast<const float4v*>(a.bias + c);
+                const float4v b1 = *reinterpret_cast<const float4v*>(a.bias + c + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { x[e] += b0[e]; x[e + 4] += b1[e]; }
+            }
+            if (a.res_mode) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] += (float)rres[i][e];
+            }
+            if (a.relu) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] = fmaxf(x[e], 0.f);
+            }
+            half8 h;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) h[e] = (_Float16)x[e];
+            *reinterpret_cast<half8*>(reinterpret_cast<_Float16*>(a.out) + (size_t)m * a.out_stride + c) = h;
+        }
+        __syncthreads();
+    }
+}
+
+template <int MODE>
+int launch_big(const Conv2Args& a0, hipStream_t st) {
+    Conv2Args a = a0;
+    a.tiles_m = pe::ceil_div(a.M, 256);
+    a.tiles_n = pe::ceil_div(a.Cout, 256);
+    constexpr size_t lds = (size_t)2 * 512 * ROW_B;  // 128 KiB (the epilogue's 65 KiB staging reuses it)
+    static bool done = false;
+    if (!done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_big_kernel<MODE>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        done = true;
+    }
+    hipLaunchKernelGGL((conv_big_kernel<MODE>), dim3(a.tiles_m * a.tiles_n), dim3(512), lds, st, a);
+    PE_CHECK_LAUNCH("pe_conv2d_nhwc_f16(256x256)");
+    return PE_OK;
+}
+
 template <int BM, int BN, int MODE, int STAGES = 1>
 int launch2(const Conv2Args& a0, hipStream_t st) {
     Conv2Args a = a0;
@@ -460,7 +666,8 @@ int launch2(const Conv2Args& a0, hipStream_t st) {
 
 namespace pe {
 int g_conv_ablate = 0;
-int g_conv_tile256 = 1;  // bit 0: 256-row tiles for big 3x3 launches, bit 1: for big 1x1 launches, bit 2: two-stage 1x1 pipeline
+int g_conv_tile256 = 9;  // bit 0: 256-row tiles for big 3x3 launches, bit 1: for big 1x1 launches, bit 2: two-stage 1x1 pipeline,
+                          // bit 3: 256x256 two-stage kernel for long-K GEMMs, bit 4: ... for every eligible launch
 int g_conv3x3_reuse = 1;  // pe_set_conv_impl(3) turns the kw-reuse 3x3 kernel off (A/B measurements)
 // called from pe_conv2d_nhwc_f16 (conv_igemm.hip) for the 1x1 / 3x3 cases
 int conv2_dispatch(const void* in, const void* wgt, const float* bias, const void* res, void* out, int N, int H, int W,
@@ -472,6 +679,12 @@ int conv2_dispatch(const void* in, const void* wgt, const float* bias, const voi
     a.relu = relu; a.res_mode = res_mode; a.resH = resH; a.resW = resW; a.out_f32 = out_f32;
     a.cout_store = cout_store; a.out_stride = out_stride; a.ablate = g_conv_ablate;
     const bool narrow = Cout <= 64;
+    // 256 x 256 two-stage kernel: fp16 output, whole 256-channel tiles, a grid that fills the 256 CUs
+    // (measured r01: +24 % on the K = 12544 FC GEMM, neutral-to-negative on the convolutions -> long-K GEMMs only;
+    //  policy bit 4 forces it everywhere it applies, for A/B runs)
+    if ((g_conv_tile256 & 8) && !out_f32 && Cout % 256 == 0 && cout_store == Cout &&
+        (long long)pe::ceil_div(M, 256) * (Cout / 256) >= 224 && ((g_conv_tile256 & 16) || (!mode3x3 && K >= 4096)))
+        return mode3x3 ? launch_big<MODE_3X3>(a, st) : launch_big<MODE_1X1>(a, st);
     if (mode3x3 && g_conv3x3_reuse) {
         if (narrow) return launch3x3r<128, 64>(a, st);
         // 256-row tiles (8 waves) halve the weight-tile traffic per flop; keep 128 when the grid would not fill the chip

@@ -151,7 +151,7 @@ def conv2d_nhwc(x, weight, bias, *, kernel, stride=1, relu=False, residual=None,
                                        int(out_f32), int(cout_store), int(out_stride), _lib.stream())
     _lib.check(st, "pe_conv2d_nhwc_f16")
     if PROFILE is not None:  # bench.py roofline leg: remember the launch so it can be replayed back-to-back
-        variant = conv_variant_name(N * Ho * Wo, Cout, kernel)
+        variant = conv_variant_name(N * Ho * Wo, Cout, kernel, Cin if kernel == 1 else 0)
         cin_real = 3 if kernel == 7 else Cin
         shape = f"N{N} {H}x{W} Cin{Cin} Cout{Cout} k{kernel} s{stride} res{residual_mode} f32{int(out_f32)}"
         M = N * Ho * Wo
@@ -165,14 +165,16 @@ def conv2d_nhwc(x, weight, bias, *, kernel, stride=1, relu=False, residual=None,
     return out
 
 
-def conv_variant_name(M, Cout, kernel):
+def conv_variant_name(M, Cout, kernel, K=0):
     """Name of the kernel pe_conv2d_nhwc_f16 dispatches to (mirrors conv2_dispatch in csrc/conv_igemm2.hip;
     matches the rocprofv3 kernel names)."""
     bn = 64 if Cout <= 64 else 128
     if kernel == 7:
         return "conv_igemm_kernel<128, 64, 2>"          # 7x7 stem, register-staged kernel
     if kernel == 1:
-        return f"conv_igemm2_kernel<128, {bn}, 0>"      # LDS-DMA 1x1 / GEMM
+        if K >= 4096 and Cout % 256 == 0 and ((M + 255) // 256) * (Cout // 256) >= 224:
+            return "conv_big_kernel<0>"                 # 256x256 two-stage kernel (long-K GEMM: fc1)
+        return f"conv_igemm2_kernel<128, {bn}, 0, 1>"   # LDS-DMA 1x1 / GEMM
     if bn == 64:
         return "conv3x3r_kernel<128, 64, 0>"
     big = ((M + 255) // 256) * ((Cout + 127) // 128) >= 512

@@ -33,7 +33,7 @@ def main():
         out = torch.empty(N, H, W, Cout, device="cuda", dtype=torch.float16)
         fl = 2.0 * N * H * W * Cout * k * k * Cin
         row = []
-        for impl, abl, tile in [(1, 0, 1), (3, 0, 1), (2, 0, 0), (2, 0, 1), (2, 0, 3), (2, 0, 4), (2, 0, 7), (2, 1, 1), (2, 2, 1)]:
+        for impl, abl, tile in [(1, 0, 1), (3, 0, 1), (2, 0, 0), (2, 0, 1), (2, 0, 3), (2, 0, 25), (2, 1, 1), (2, 2, 1)]:
             lib.pe_set_conv_impl(impl)
             lib.pe_set_conv_ablation(abl)
             lib.pe_set_conv_tile256(tile)
@@ -41,7 +41,7 @@ def main():
             row.append(f"i{impl}a{abl}t{tile}: {ms:.4f}ms {fl / ms / 1e9:6.0f}TF")
         lib.pe_set_conv_impl(2)
         lib.pe_set_conv_ablation(0)
-        lib.pe_set_conv_tile256(1)
+        lib.pe_set_conv_tile256(9)
         print(f"N{N} {H}x{W} {Cin}->{Cout} k{k} | " + " | ".join(row), flush=True)
 
 

@@ -69,6 +69,38 @@ def test_conv_matches_torch(L, case):
     torch.testing.assert_close(got, ref, **tol)
 
 
+@pytest.mark.parametrize("case", [(8, 100, 128, 128, 256, 3, 1, True, 0), (9, 99, 131, 256, 512, 1, 1, True, 1),
+                                  (8, 100, 128, 256, 256, 1, 1, False, 2), (16, 51, 64, 512, 256, 1, 2, False, 0)])
+def test_conv_big_tile_kernel(L, case):
+    """The 256x256 two-stage kernel (tile policy bit 3) against torch, incl. ragged M, residual modes, stride 2."""
+    import proben_amd
+    N, H, W, Cin, Cout, k, s, relu, res_mode = case
+    lib = proben_amd._lib.lib()
+    g = torch.Generator(device="cpu").manual_seed(11)
+    x = torch.randn(N, Cin, H, W, generator=g).cuda().half()
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).cuda().half()
+    b = torch.randn(Cout, generator=g).cuda()
+    ref = torch.nn.functional.conv2d(x.float(), w.float(), b, stride=s, padding=k // 2)
+    res = None
+    if res_mode == 1:
+        res = torch.randn(ref.shape, generator=g).cuda().half()
+        ref = ref + res.float()
+        res = nhwc(res)
+    elif res_mode == 2:
+        res = torch.randn(N, Cout, (ref.shape[2] + 1) // 2, (ref.shape[3] + 1) // 2, generator=g).cuda().half()
+        ref = ref + torch.nn.functional.interpolate(res.float(), scale_factor=2, mode="nearest")[:, :, : ref.shape[2], : ref.shape[3]]
+        res = nhwc(res)
+    if relu:
+        ref = ref.relu()
+    lib.pe_set_conv_tile256(25)
+    try:
+        out = L.conv2d_nhwc(nhwc(x), w.permute(0, 2, 3, 1).contiguous(), b, kernel=k, stride=s, relu=relu, residual=res, residual_mode=res_mode)
+        torch.cuda.synchronize()
+    finally:
+        lib.pe_set_conv_tile256(9)
+    torch.testing.assert_close(out.permute(0, 3, 1, 2).float(), ref, rtol=4e-3, atol=4e-3)
+
+
 def test_conv_transpose_detecting(L):
     """A = identity-like pixels, ASYMMETRIC weights: catches a row/col swap in the MFMA C layout."""
     Cin = Cout = 128
