@@ -145,7 +145,7 @@ def roofline_leg(step, layers_path="", reps=10):
     dom = max(agg, key=lambda k: agg[k][2])
     out = with_traffic(describe(dom))
     # north_star's MFMA target is quoted on the 3x3 convolutions: always report their kernel as well
-    k3 = max((k for k in agg if k.startswith("conv3x3r")), key=lambda k: agg[k][2], default=None)
+    k3 = max((k for k in agg if k.startswith("conv3x3")), key=lambda k: agg[k][2], default=None)
     if k3 is not None and k3 != dom:
         out["conv3x3"] = with_traffic(describe(k3))
     out["all_conv_variants"] = {k: {"launches": v[0], "gflop": round(v[1] / 1e9, 1), "ms": round(v[2] * 1e3, 3),

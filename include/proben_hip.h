@@ -118,8 +118,10 @@ int pe_set_conv_impl(int32_t impl);
 /* Measurement aid (results become WRONG): 0 = normal, 1 = skip the LDS-DMA loads, 2 = skip the MFMAs of the
  * kw-reuse 3x3 kernel.  Used by scripts/ablate_conv.py only. */
 int pe_set_conv_ablation(int32_t mode);
-/* Tile policy (A/B measurements): 0 = 128-row block tiles only, 1 (default) = 256-row tiles (8 waves) for 3x3
- * launches with >= 512 such tiles, 2 = also for 1x1 launches. */
+/* Kernel-selection policy bits (A/B measurements; default 41 = 1|8|32):
+ *   1: 256-row block tiles (8 waves) for 3x3 launches with >= 512 such tiles     2: the same for 1x1 launches
+ *   4: two-stage pipeline in the generic 1x1 kernel                              8: 256x256 two-stage kernel for long-K GEMMs
+ *  16: 256x256 kernel for every eligible launch                                 32: double-buffered weight tile in the 3x3 kernel */
 int pe_set_conv_tile256(int32_t mode);
 
 /* ---------------------------------------------------------------------------------------------

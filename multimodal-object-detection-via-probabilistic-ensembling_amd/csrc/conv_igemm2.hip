@@ -19,6 +19,11 @@
 
 #include "common.h"
 
+namespace pe {
+extern int g_conv_tile256;
+}
+using pe::g_conv_tile256;
+
 namespace {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -416,6 +421,138 @@ __global__ __launch_bounds__(BM * 2, BM == 128 ? 3 : 4) void conv3x3r_kernel(Con
     epilogue<BM, BN, THREADS>(a, acc, smem, m0, n0, tid, lane, wm, wn);
 }
 
+// Same kernel with the WEIGHT tile double-buffered: tap t+1's 16 KiB B tile streams into the other LDS stage while
+// tap t feeds the MFMAs, so per (kh, chunk) group only the A slab DMA is exposed and there are 4 barriers
+// instead of 6.  LDS: slab + 2 x 16 KiB (66 KiB at BM = 256: still two 8-wave workgroups per CU).
+template <int BM, int BN>
+__global__ __launch_bounds__(BM * 2, BM == 128 ? 3 : 4) void conv3x3rb_kernel(Conv2Args a) {
+    constexpr int ABL = 0;
+    constexpr int THREADS = BM * 2, WAVES = BM / 32;   // waves as (BM/64) x 2, each 64 x (BN/2)
+    constexpr int WM = 64, WN = BN / 2;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int SLAB_ROWS = BM + 8;         // BM + 2 rounded up to a multiple of 8
+    constexpr int LAST_GROUP = BM / 8;        // DMA group holding slab rows BM .. BM+7 (wave 0's extra one)
+    constexpr int B_INSTR = BN / 8 / WAVES;
+    constexpr int A_BYTES = SLAB_ROWS * ROW_B;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int nwg = a.tiles_m * a.tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_n = bid % a.tiles_n, tile_m = bid / a.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lrow = lane >> 3, lp = lane & 7;
+
+    // slab DMA: wave w owns row groups 4w..4w+3, wave 0 also the last group (descriptors are recomputed per slab
+    // - once per three K-steps - instead of living in registers)
+    constexpr int A_INSTR = 5;
+    const _Float16* b_src[B_INSTR];
+#pragma unroll
+    for (int i = 0; i < B_INSTR; ++i) {
+        const int r = (wave * B_INSTR + i) * 8 + lrow;
+        const int n = n0 + r;
+        b_src[i] = (n < a.Cout) ? a.wgt + (size_t)n * a.K + (lp ^ ((r >> 1) & 7)) * 8 : nullptr;
+    }
+    const _Float16* zero = reinterpret_cast<const _Float16*>(g_zero_page);
+
+    // fragment rows and edge masks (per lane, per M sub-tile)
+    const int frow = lane & 31, fkh = lane >> 5;
+    bool not_left[TM], not_right[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wm * WM + i * 32 + frow;
+        const int ow = (m < a.M ? m : 0) % a.Wo;
+        not_left[i] = ow != 0;
+        not_right[i] = ow != a.Wo - 1;
+    }
+    const unsigned char* lb = smem + A_BYTES + (wn * WN + frow) * ROW_B;
+    const int fswb = (frow >> 1) & 7;
+
+    float16v acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+    constexpr int B_BYTES = BN * ROW_B;
+    const int chunks = a.Cin / BK;
+    const int groups = 3 * chunks;
+    auto dma_b = [&](int tap_k0, int stage) {
+#pragma unroll
+        for (int i = 0; i < B_INSTR; ++i) {
+            const _Float16* p = b_src[i] ? b_src[i] + tap_k0 : zero;
+            __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(smem + A_BYTES + stage * B_BYTES + (wave * B_INSTR + i) * 1024), 16, 0, 0);
+        }
+    };
+    dma_b(0, 0);  // weight tile of the very first tap
+    int g = 0;    // running tap counter: tap g uses B stage g & 1
+    for (int grp = 0; grp < groups; ++grp) {
+        const int kh = grp / chunks, cc = grp - kh * chunks;
+        const int c0 = cc * BK;
+        // ---- A slab for (kh, chunk); every wave finished reading the previous slab at the barrier below ----
+#pragma unroll
+        for (int i = 0; i < A_INSTR; ++i) {
+            if (i == 4 && wave != 0) continue;  // wave-uniform
+            const int gg = i < 4 ? wave * 4 + i : LAST_GROUP;
+            const int j = gg * 8 + lrow;
+            const int m = m0 + j - 1;
+            bool ok = m >= 0 && m < a.M && j < BM + 2;
+            const int mm = ok ? m : 0;
+            const int ih = (mm / a.Wo) % a.Ho + kh - 1;
+            ok = ok && (unsigned)ih < (unsigned)a.H;
+            const _Float16* p = ok ? a.in + (size_t)(mm + (kh - 1) * a.W) * a.Cin + c0 + (lp ^ ((j >> 1) & 7)) * 8 : zero;
+            __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(smem + gg * 1024), 16, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            // prefetch the NEXT tap's weight tile into the other stage
+            if (kw < 2) {
+                dma_b((kh * 3 + kw + 1) * a.Cin + c0, (g + 1) & 1);
+            } else if (grp + 1 < groups) {
+                const int nkh = (grp + 1) / chunks, ncc = (grp + 1) - nkh * chunks;
+                dma_b((nkh * 3) * a.Cin + ncc * BK, (g + 1) & 1);
+            }
+            const unsigned char* lbs = lb + (g & 1) * B_BYTES;
+            const int arow0 = wm * WM + frow + kw;
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                half8 af[TM], bf[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int r = arow0 + i * 32;
+                    const int ch = ((ks * 2 + fkh) ^ ((r >> 1) & 7)) << 4;
+                    af[i] = *reinterpret_cast<const half8*>(smem + r * ROW_B + ch);
+                    if (kw == 0) af[i] = not_left[i] ? af[i] : zero8;
+                    if (kw == 2) af[i] = not_right[i] ? af[i] : zero8;
+                }
+                const int chb = ((ks * 2 + fkh) ^ fswb) << 4;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const half8*>(lbs + j * 32 * ROW_B + chb);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+            }
+            ++g;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();  // next weight tile landed; this tap's LDS reads retired
+        }
+    }
+    epilogue<BM, BN, THREADS>(a, acc, smem, m0, n0, tid, lane, wm, wn);
+}
+
 template <int BM, int BN>
 int launch3x3r(const Conv2Args& a0, hipStream_t st) {
     Conv2Args a = a0;
@@ -425,6 +562,21 @@ int launch3x3r(const Conv2Args& a0, hipStream_t st) {
     constexpr size_t epi = (size_t)64 * (BN + 4) * 4;
     constexpr size_t lds = stage > epi ? stage : epi;
     const dim3 grid(a.tiles_m * a.tiles_n), block(BM * 2);
+    if (a.ablate == 0 && (g_conv_tile256 & 32)) {
+        constexpr size_t stage_b = (size_t)(BM + 8 + 2 * BN) * ROW_B;
+        constexpr size_t lds_b = stage_b > epi ? stage_b : epi;
+        if (lds_b > 64 * 1024) {
+            static bool done = false;
+            if (!done) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3rb_kernel<BM, BN>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
+                done = true;
+            }
+        }
+        hipLaunchKernelGGL((conv3x3rb_kernel<BM, BN>), grid, block, lds_b, st, a);
+        PE_CHECK_LAUNCH("pe_conv2d_nhwc_f16(3x3 row-reuse, B double-buffered)");
+        return PE_OK;
+    }
     if (a.ablate == 1)
         hipLaunchKernelGGL((conv3x3r_kernel<BM, BN, 1>), grid, block, lds, st, a);
     else if (a.ablate == 2)
@@ -666,8 +818,9 @@ int launch2(const Conv2Args& a0, hipStream_t st) {
 
 namespace pe {
 int g_conv_ablate = 0;
-int g_conv_tile256 = 9;  // bit 0: 256-row tiles for big 3x3 launches, bit 1: for big 1x1 launches, bit 2: two-stage 1x1 pipeline,
-                          // bit 3: 256x256 two-stage kernel for long-K GEMMs, bit 4: ... for every eligible launch
+int g_conv_tile256 = 41;  // bit 0: 256-row tiles for big 3x3 launches, bit 1: for big 1x1 launches, bit 2: two-stage 1x1 pipeline,
+                          // bit 3: 256x256 two-stage kernel for long-K GEMMs, bit 4: ... for every eligible launch,
+                          // bit 5: double-buffered weight tile in the kw-reuse 3x3 kernel
 int g_conv3x3_reuse = 1;  // pe_set_conv_impl(3) turns the kw-reuse 3x3 kernel off (A/B measurements)
 // called from pe_conv2d_nhwc_f16 (conv_igemm.hip) for the 1x1 / 3x3 cases
 int conv2_dispatch(const void* in, const void* wgt, const float* bias, const void* res, void* out, int N, int H, int W,

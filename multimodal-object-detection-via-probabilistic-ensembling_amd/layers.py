@@ -176,9 +176,9 @@ def conv_variant_name(M, Cout, kernel, K=0):
             return "conv_big_kernel<0>"                 # 256x256 two-stage kernel (long-K GEMM: fc1)
         return f"conv_igemm2_kernel<128, {bn}, 0, 1>"   # LDS-DMA 1x1 / GEMM
     if bn == 64:
-        return "conv3x3r_kernel<128, 64, 0>"
+        return "conv3x3rb_kernel<128, 64>"
     big = ((M + 255) // 256) * ((Cout + 127) // 128) >= 512
-    return f"conv3x3r_kernel<{256 if big else 128}, 128, 0>"  # kw-reuse 3x3
+    return f"conv3x3rb_kernel<{256 if big else 128}, 128>"  # kw-reuse 3x3, double-buffered weight tile
 
 
 def linear_f16(x, weight, bias, *, relu=False, out_f32=False, cout_store=0, out_stride=0):

@@ -97,7 +97,30 @@ def test_conv_big_tile_kernel(L, case):
         out = L.conv2d_nhwc(nhwc(x), w.permute(0, 2, 3, 1).contiguous(), b, kernel=k, stride=s, relu=relu, residual=res, residual_mode=res_mode)
         torch.cuda.synchronize()
     finally:
-        lib.pe_set_conv_tile256(9)
+        lib.pe_set_conv_tile256(41)
+    torch.testing.assert_close(out.permute(0, 3, 1, 2).float(), ref, rtol=4e-3, atol=4e-3)
+
+
+@pytest.mark.parametrize("case", [(16, 100, 128, 128, 128, 3, 1, True, 0), (9, 99, 131, 64, 256, 3, 1, False, 0),
+                                  (2, 25, 32, 256, 256, 3, 1, True, 0), (3, 40, 50, 64, 64, 3, 1, True, 0)])
+def test_conv3x3_weight_double_buffered_kernel(L, case):
+    """The kw-reuse 3x3 kernel with the double-buffered weight tile (tile policy bit 5), 128- and 256-row tiles."""
+    import proben_amd
+    N, H, W, Cin, Cout, k, s, relu, _ = case
+    lib = proben_amd._lib.lib()
+    g = torch.Generator(device="cpu").manual_seed(13)
+    x = torch.randn(N, Cin, H, W, generator=g).cuda().half()
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).cuda().half()
+    b = torch.randn(Cout, generator=g).cuda()
+    ref = torch.nn.functional.conv2d(x.float(), w.float(), b, stride=s, padding=1)
+    if relu:
+        ref = ref.relu()
+    lib.pe_set_conv_tile256(9 | 32)
+    try:
+        out = L.conv2d_nhwc(nhwc(x), w.permute(0, 2, 3, 1).contiguous(), b, kernel=k, stride=s, relu=relu)
+        torch.cuda.synchronize()
+    finally:
+        lib.pe_set_conv_tile256(41)
     torch.testing.assert_close(out.permute(0, 3, 1, 2).float(), ref, rtol=4e-3, atol=4e-3)
 
 
