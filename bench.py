@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--cpu-pairs", type=int, default=8)
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--conv-impl", type=int, default=2, help="1: register-staged conv kernel, 2: LDS-DMA conv kernel")
+    ap.add_argument("--serial-detectors", action="store_true", help="run the two detectors back to back on one stream")
     ap.add_argument("--tile256", type=int, default=-1, help="conv tile policy override (pe_set_conv_tile256)")
     ap.add_argument("--layers", type=str, default="", help="write a per-conv-launch table (shape, ms, TFLOP/s) to this file")
     return ap.parse_args()
@@ -55,16 +56,14 @@ def build_models(depth, device):
     return models, sds
 
 
-def make_step(models, frames_t, frames_rgb, world, rank, with_comm=True):
-    from proben_amd import fusion as F
+def make_step(models, frames_t, frames_rgb, world, rank, with_comm=True, concurrent=True):
+    from proben_amd.pipeline import FramePairPipeline
     B = frames_t.shape[0]
     out_sizes = [(512, 640)] * B
-    ft, fr = frames_t, frames_rgb  # [B,512,640,3] uint8 batches, one preprocess launch each
+    pipe = FramePairPipeline(models, "probEn", "v-avg", concurrent=concurrent)
 
     def step():
-        det_t = models[0].forward_batch(ft, out_sizes=out_sizes, resize_to=(800, 1000))
-        det_r = models[1].forward_batch(fr, out_sizes=out_sizes, resize_to=(800, 1000))
-        fused = F.fuse_detections([det_t, det_r], "probEn", "v-avg")
+        (det_t, det_r), fused = pipe([frames_t, frames_rgb], out_sizes, (800, 1000))  # [B,512,640,3] uint8 batches
         if world > 1 and with_comm:
             from proben_amd import comm
             comm.all_gather_fused_rows(fused)
@@ -206,7 +205,7 @@ def main():
     B = args.batch
     frames_t = torch.from_numpy(synthetic_images(B, seed=10 + rank)).to(dev)
     frames_rgb = torch.from_numpy(synthetic_images(B, seed=1000 + rank)).to(dev)
-    step = make_step(models, frames_t, frames_rgb, world, rank)
+    step = make_step(models, frames_t, frames_rgb, world, rank, concurrent=not args.serial_detectors)
 
     def fence():
         if world > 1:
@@ -244,7 +243,7 @@ def main():
         }
         if not args.no_roofline:
             # rank-local leg: no collective inside (the other ranks are already waiting at the final barrier)
-            line["roofline"] = roofline_leg(make_step(models, frames_t, frames_rgb, world, rank, with_comm=False), args.layers)
+            line["roofline"] = roofline_leg(make_step(models, frames_t, frames_rgb, world, rank, with_comm=False, concurrent=False), args.layers)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(sds, args.depth, args.cpu_pairs, args.cpu_threads)
         print(json.dumps(line), flush=True)

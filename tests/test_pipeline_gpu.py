@@ -95,3 +95,30 @@ def test_predictor_and_device_stage_fusion():
         np.testing.assert_array_equal(fused["classes"][sl].cpu().numpy(), c.numpy())
         np.testing.assert_allclose(fused["scores"][sl].cpu().numpy(), s.numpy(), rtol=1e-6, equal_nan=True)
         np.testing.assert_allclose(fused["boxes"][sl].cpu().numpy(), np.asarray(b), rtol=1e-9, atol=1e-9, equal_nan=True)
+
+
+def test_frame_pair_pipeline_concurrent_equals_serial():
+    """Detectors on separate HIP streams (the bench configuration) give bit-identical results to the serial run."""
+    import proben_amd  # noqa: F401
+    from proben_amd.pipeline import FramePairPipeline
+    from proben_amd.rcnn import DetectorConfig, GeneralizedRCNN
+    from proben_amd.synthetic import synthetic_images, synthetic_state_dict
+    models = [GeneralizedRCNN(DetectorConfig(), synthetic_state_dict(50, 3, 3, seed=s)) for s in (1, 2)]
+    ft = torch.from_numpy(synthetic_images(4, 256, 320, seed=7)).cuda()
+    fr = torch.from_numpy(synthetic_images(4, 256, 320, seed=8)).cuda()
+    outs = []
+    for concurrent in (False, True, True):
+        pipe = FramePairPipeline(models, "probEn", "v-avg", concurrent=concurrent)
+        dets, fused = pipe([ft, fr], [(256, 320)] * 4, (800, 1000))
+        torch.cuda.synchronize()
+        outs.append((dets, fused))
+    (d0, f0) = outs[0]
+    for d1, f1 in outs[1:]:
+        for a, b in zip(d0, d1):
+            assert torch.equal(a["counts"], b["counts"])
+            for i, c in enumerate(a["counts"].tolist()):
+                assert torch.equal(a["boxes"][i, :c], b["boxes"][i, :c]) and torch.equal(a["scores"][i, :c], b["scores"][i, :c])
+        assert torch.equal(f0["counts"], f1["counts"])
+        off, cnt = f0["offsets"].tolist(), f0["counts"].tolist()
+        for o, c in zip(off, cnt):
+            assert torch.equal(f0["boxes"][o:o + c], f1["boxes"][o:o + c]) and torch.equal(f0["scores"][o:o + c], f1["scores"][o:o + c])
