@@ -147,3 +147,19 @@ def test_kaist_rows():
     inst.pred_boxes = Boxes(torch.tensor([[10.0, 20.0, 30.0, 60.0]]))
     inst.scores = torch.tensor([0.5])
     assert demo_LAMR_KAIST.kaist_rows(0, inst) == ["1,10.0000,20.0000,20.0000,40.0000,0.50000000"]
+
+
+def test_log_average_miss_rate_properties():
+    """KAIST metric (parity unpinned - the reference's evaluator is missing from its tree): known-answer cases."""
+    gt = [[(10, 10, 20, 40, 0), (100, 50, 20, 40, 0)], [(30, 30, 25, 50, 0)], [(5, 5, 10, 20, 1)]]
+    perfect = [[(10, 10, 20, 40, 0.9), (100, 50, 20, 40, 0.8)], [(30, 30, 25, 50, 0.95)], [(5, 5, 10, 20, 0.99)]]
+    lamr, mr, pts = evaluation.log_average_miss_rate(gt, perfect)
+    assert lamr == pytest.approx(1e-10) and np.all(mr == 0)          # everything found, the ignore match is free
+    none = [[], [], []]
+    assert evaluation.log_average_miss_rate(gt, none)[0] == pytest.approx(1.0)
+    # one miss out of three and one high-scoring false positive: MR = 1/3 once FPPI >= 1/3, 1.0 below... the FP
+    # outranks everything, so at FPPI < 1/3 nothing is counted yet
+    dets = [[(10, 10, 20, 40, 0.9)], [(30, 30, 25, 50, 0.8), (200, 200, 20, 40, 0.99)], []]
+    lamr2, mr2, pts2 = evaluation.log_average_miss_rate(gt, dets)
+    assert np.all(mr2[pts2 < 1 / 3] == 1.0) and np.allclose(mr2[pts2 >= 1 / 3], 1 / 3)
+    assert 1 / 3 < lamr2 < 1.0

@@ -122,3 +122,53 @@ def test_frame_pair_pipeline_concurrent_equals_serial():
         off, cnt = f0["offsets"].tolist(), f0["counts"].tolist()
         for o, c in zip(off, cnt):
             assert torch.equal(f0["boxes"][o:o + c], f1["boxes"][o:o + c]) and torch.equal(f0["scores"][o:o + c], f1["scores"][o:o + c])
+
+
+def test_cli_end_to_end_on_synthetic_dataset(tmp_path):
+    """save_predictions (x2 methods) -> val_<method>_predictions.json -> demo_probEn -> AP table, on a synthetic
+    FLIR-shaped dataset written as real JPEG files (the reference's directory layout and file names)."""
+    import json
+    from PIL import Image
+    from proben_amd.cli import demo_probEn, save_predictions
+    from proben_amd.synthetic import synthetic_images
+    root = tmp_path / "val"
+    (root / "thermal_8_bit").mkdir(parents=True)
+    (root / "RGB").mkdir()
+    n, H, W = 6, 256, 320
+    th, rgb = synthetic_images(n, H, W, seed=21), synthetic_images(n, H + 40, W + 60, seed=22)
+    images, anns = [], []
+    for i in range(n):
+        Image.fromarray(th[i]).save(root / "thermal_8_bit" / f"FLIR_{i:05d}.jpeg", quality=95)
+        Image.fromarray(rgb[i]).save(root / "RGB" / f"FLIR_{i:05d}.jpg", quality=95)
+        images.append({"id": i, "file_name": f"thermal_8_bit/FLIR_{i:05d}.jpeg", "height": H, "width": W})
+        anns.append({"id": i + 1, "image_id": i, "category_id": 1 + i % 3, "bbox": [20, 30, 60, 80], "area": 4800, "iscrowd": 0})
+    json.dump({"images": images, "annotations": anns, "categories": [{"id": 1, "name": "person"}, {"id": 2, "name": "bicycle"},
+                                                                      {"id": 3, "name": "car"}]},
+              open(root / "FLIR_thermal_RGBT_pairs_val.json", "w"))
+    pred = tmp_path / "pred"
+    for method in ("thermal_only", "early_fusion"):
+        save_predictions.main(["--dataset_path", str(root), "--prediction_path", str(pred), "--fusion_method", method,
+                               "--batch", "4", "--outfolder", str(tmp_path / "out")])
+        d = json.load(open(pred / f"val_{method}_predictions.json"))
+        assert list(d) == ["image", "boxes", "scores", "classes", "image_id", "class_logits", "probs", "vars"] and len(d["image"]) == n
+    res = demo_probEn.main(["--dataset_path", str(root), "--prediction_path", str(pred), "--outfolder", str(tmp_path / "out"),
+                            "--detectors", "thermal_only,early_fusion", "--score_fusion", "probEn", "--box_fusion", "v-avg",
+                            "--dataset_name", "flir_cli_test"])
+    assert "bbox" in res and "AP50" in res["bbox"]
+
+
+def test_kaist_single_class_pipeline():
+    """Config 5 shape: K = 1 detectors (R50-FPN) + the binary ProbEn form (demo_probEn.py:24-30)."""
+    import proben_amd  # noqa: F401
+    from proben_amd.pipeline import FramePairPipeline
+    from proben_amd.rcnn import DetectorConfig, GeneralizedRCNN
+    from proben_amd.synthetic import synthetic_images, synthetic_state_dict
+    models = [GeneralizedRCNN(DetectorConfig(num_classes=1), synthetic_state_dict(50, 1, 3, seed=s)) for s in (3, 4)]
+    fr = [torch.from_numpy(synthetic_images(2, 256, 320, seed=9 + i)).cuda() for i in range(2)]
+    dets, fused = FramePairPipeline(models, "probEn_binary", "v-avg", max_class=0)(fr, [(256, 320)] * 2, (800, 1000))
+    assert dets[0]["prob_score"].shape[2] == 1 and dets[0]["class_logits"].shape[2] == 2
+    c = fused["counts"].tolist()
+    assert all(x >= 0 for x in c)
+    for o, n in zip(fused["offsets"].tolist(), c):
+        s = fused["scores"][o:o + n]
+        assert bool(((s >= 0) & (s <= 1)).all()) and bool((fused["classes"][o:o + n] == 0).all())
