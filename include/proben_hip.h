@@ -184,7 +184,11 @@ int pe_rpn_select_topk(const float* const* level_heads_host, const int32_t* leve
                        const int32_t* level_stride_host, const float* cell_anchors_host,
                        int32_t num_levels, int32_t N, int32_t head_stride, int32_t pre_nms_topk,
                        const int32_t* image_hw, float scale_clamp, float* cand_boxes, float* cand_scores,
-                       int32_t* cand_level, uint8_t* cand_valid, int32_t cand_per_image, void* stream);
+                       int32_t* cand_level, uint8_t* cand_valid, int32_t cand_per_image, void* scratch,
+                       size_t scratch_bytes, void* stream);
+/* Optional scratch for pe_rpn_select_topk: with >= this many bytes, levels larger than 16384 anchors are selected in
+ * two exact stages (per-slice top-k on many CUs, then a merge) instead of one workgroup per (image, level). */
+size_t pe_rpn_scratch_bytes(const int32_t* level_hw_host, int32_t num_levels, int32_t N);
 int pe_gather_boxes(const float* boxes, const float* scores, const int32_t* keep, const int32_t* counts,
                     int32_t N, int32_t n_in, int32_t max_out, float* out_boxes, float* out_scores,
                     void* stream);

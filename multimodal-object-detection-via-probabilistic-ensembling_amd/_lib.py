@@ -26,13 +26,14 @@ SIGNATURES = {
     "pe_subsample2_nhwc": [c_void_p] * 2 + [c_int] * 4 + [c_void_p],
     "pe_nms_scratch_bytes": [c_int, c_int],
     "pe_nms_batched": [c_void_p] * 5 + [c_int, c_int, c_float, c_int, c_int] + [c_void_p] * 3 + [c_size_t, c_void_p],
-    "pe_rpn_select_topk": [c_void_p] * 4 + [c_int] * 4 + [c_void_p, c_float] + [c_void_p] * 4 + [c_int, c_void_p],
+    "pe_rpn_select_topk": [c_void_p] * 4 + [c_int] * 4 + [c_void_p, c_float] + [c_void_p] * 4 + [c_int, c_void_p, c_size_t, c_void_p],
+    "pe_rpn_scratch_bytes": [c_void_p, c_int, c_int],
     "pe_gather_boxes": [c_void_p] * 4 + [c_int] * 3 + [c_void_p] * 3,
     "pe_roi_align_nhwc": [c_void_p] * 3 + [c_int] * 4 + [c_void_p] + [c_int] * 3 + [c_void_p] + [c_int] * 4 + [c_void_p] * 3,
     "pe_boxhead_candidates": [c_void_p, c_int, c_int, c_int, c_int] + [c_void_p] * 4 + [c_float, c_float, c_int] + [c_void_p] * 7,
     "pe_boxhead_finalize": [c_void_p] + [c_int] * 7 + [c_void_p] * 18,
 }
-_RESTYPE = {"pe_last_error": ctypes.c_char_p, "pe_nms_scratch_bytes": ctypes.c_size_t}
+_RESTYPE = {"pe_last_error": ctypes.c_char_p, "pe_nms_scratch_bytes": ctypes.c_size_t, "pe_rpn_scratch_bytes": ctypes.c_size_t}
 
 
 class HipLibraryError(RuntimeError):

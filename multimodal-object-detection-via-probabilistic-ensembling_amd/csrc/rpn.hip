@@ -16,10 +16,12 @@ namespace {
 constexpr int kThreads = 1024;
 constexpr int kMaxTopk = 1024;
 constexpr int kA = 3;
+constexpr int kSlice = 16384;  // anchors per stage-1 slice
 
 struct RpnLevel {
     const float* head;  // [N*H*W, head_stride]
     int H, W, stride;
+    int first_slice, num_slices;  // stage-1 slices of this level (num_slices <= 1: single-stage)
     int topk;           // min(pre_nms_topk, H*W*A)
     int cand_offset;    // offset of this level inside an image's candidate list
     float cell[kA][4];  // cell anchors (float32 of the float64 closed form)
@@ -35,6 +37,10 @@ struct RpnArgs {
     float* cand_scores;    // [N, cand_per_image]
     int32_t* cand_level;   // [N, cand_per_image]
     uint8_t* cand_valid;   // [N, cand_per_image]
+    // two-stage selection (optional scratch)
+    unsigned long long* slice_out;  // [N, num_slices, 1024]
+    int num_slices;
+    int slice_level[64], slice_begin[64];
 };
 
 __device__ __forceinline__ unsigned ordered_desc(float s) {
@@ -44,20 +50,14 @@ __device__ __forceinline__ unsigned ordered_desc(float s) {
     return ~u;
 }
 
-__global__ __launch_bounds__(kThreads) void rpn_select_kernel(RpnArgs a) {
-    __shared__ unsigned hist[256];
-    __shared__ unsigned long long cand[kMaxTopk];
-    __shared__ unsigned s_prefix, s_kth, s_cnt, s_base;
-    __shared__ unsigned wave_cnt[kThreads / 64];
+// Block-wide exact top-k (k <= 1024) of `total` 32-bit keys (smaller key = better) read through key_at(i):
+// 4-pass 8-bit radix select of the k-th key, then the k winners - ties broken by LOWER index i - end up in
+// cand[0..k) as (key << 32 | i), sorted ascending.  cand[k..1024) is padded with ~0.
+template <typename KeyAt>
+__device__ __forceinline__ void block_topk(int total, int k, KeyAt key_at, unsigned long long* cand, unsigned* hist,
+                                           unsigned* wave_cnt, unsigned* s4) {
     const int tid = threadIdx.x;
-    const int L = blockIdx.x, n = blockIdx.y;
-    const RpnLevel& lv = a.lv[L];
-    const int total = lv.H * lv.W * kA;
-    const int k = lv.topk;
-    const float* head = lv.head + (size_t)n * lv.H * lv.W * a.head_stride;
-    auto key_at = [&](int i) { return ordered_desc(head[(size_t)(i / kA) * a.head_stride + (i % kA)]); };
-
-    // ---- radix select: find the k-th smallest key T and how many keys are < T ----
+    unsigned &s_prefix = s4[0], &s_cnt = s4[1], &s_base = s4[2];
     unsigned prefix = 0, prefix_mask = 0, below = 0;  // `below` = #keys with key < (prefix bucket so far)
     for (int shift = 24; shift >= 0; shift -= 8) {
         for (int i = tid; i < 256; i += kThreads) hist[i] = 0;
@@ -84,17 +84,15 @@ __global__ __launch_bounds__(kThreads) void rpn_select_kernel(RpnArgs a) {
     }
     const unsigned T = prefix;               // k-th smallest key
     const unsigned need_eq = k - below;      // how many keys == T to take (lowest indices first)
-    // ---- collect keys < T (any order) ----
     if (tid == 0) s_cnt = 0;
     __syncthreads();
-    for (int i = tid; i < total; i += kThreads) {
+    for (int i = tid; i < total; i += kThreads) {  // keys < T, any order (sorted below)
         const unsigned key = key_at(i);
         if (key < T) cand[atomicAdd(&s_cnt, 1u)] = ((unsigned long long)key << 32) | (unsigned)i;
     }
-    // ---- keys == T in index order: ordered block compaction, chunk by chunk ----
     if (tid == 0) s_base = 0;
     __syncthreads();
-    for (int c0 = 0; c0 < total; c0 += kThreads) {
+    for (int c0 = 0; c0 < total; c0 += kThreads) {  // keys == T in index order: ordered block compaction
         if (s_base >= need_eq) break;  // block-uniform (read after the barrier at the loop end)
         const int i = c0 + tid;
         const bool eq = i < total && key_at(i) == T;
@@ -114,11 +112,10 @@ __global__ __launch_bounds__(kThreads) void rpn_select_kernel(RpnArgs a) {
         __syncthreads();
     }
     __syncthreads();
-    // ---- bitonic sort of the k candidates (pad to 1024 with +inf keys) ----
     for (int i = tid; i < kMaxTopk; i += kThreads)
         if (i >= k) cand[i] = ~0ull;
     __syncthreads();
-    for (int kk = 2; kk <= kMaxTopk; kk <<= 1) {
+    for (int kk = 2; kk <= kMaxTopk; kk <<= 1) {  // bitonic sort of the 1024 slots
         for (int j = kk >> 1; j > 0; j >>= 1) {
             const int i = tid, ixj = i ^ j;
             if (ixj > i) {
@@ -128,6 +125,55 @@ __global__ __launch_bounds__(kThreads) void rpn_select_kernel(RpnArgs a) {
             }
             __syncthreads();
         }
+    }
+}
+
+// Stage 1 (optional, for big levels): every slice of kSlice anchors finds ITS top-k on its own workgroup, so the
+// 153 600-key p2 level is spread over 10 CUs instead of being one workgroup's 5 passes.  Any global top-k element
+// is in its slice's top-k, so stage 2 (below) stays exact.  Output: (key << 32 | global anchor index) per slice.
+__global__ __launch_bounds__(kThreads) void rpn_slice_kernel(RpnArgs a) {
+    __shared__ unsigned hist[256];
+    __shared__ unsigned long long cand[kMaxTopk];
+    __shared__ unsigned s4[4];
+    __shared__ unsigned wave_cnt[kThreads / 64];
+    const int sl = blockIdx.x, n = blockIdx.y;
+    const int L = a.slice_level[sl];
+    const RpnLevel& lv = a.lv[L];
+    const int total_l = lv.H * lv.W * kA;
+    const int s0 = a.slice_begin[sl];
+    const int total = min(kSlice, total_l - s0);
+    const int k = min(lv.topk, total);
+    const float* head = lv.head + (size_t)n * lv.H * lv.W * a.head_stride;
+    auto key_at = [&](int i) { const int g = s0 + i; return ordered_desc(head[(size_t)(g / kA) * a.head_stride + (g % kA)]); };
+    block_topk(total, k, key_at, cand, hist, wave_cnt, s4);
+    unsigned long long* out = a.slice_out + ((size_t)n * a.num_slices + sl) * kMaxTopk;
+    const int tid = threadIdx.x;
+    out[tid] = tid < k ? ((cand[tid] & 0xFFFFFFFF00000000ull) | (unsigned)(s0 + (int)(cand[tid] & 0xFFFFFFFFu))) : ~0ull;
+}
+
+__global__ __launch_bounds__(kThreads) void rpn_select_kernel(RpnArgs a) {
+    __shared__ unsigned hist[256];
+    __shared__ unsigned long long cand[kMaxTopk];
+    __shared__ unsigned s4[4];
+    __shared__ unsigned wave_cnt[kThreads / 64];
+    const int tid = threadIdx.x;
+    const int L = blockIdx.x, n = blockIdx.y;
+    const RpnLevel& lv = a.lv[L];
+    const int k = lv.topk;
+    const float* head = lv.head + (size_t)n * lv.H * lv.W * a.head_stride;
+    if (a.slice_out && lv.num_slices > 1) {
+        // stage 2: exact top-k of the slices' winners.  The compact list is ordered (slice, rank): among equal keys a
+        // lower compact index is a lower anchor index, so the tie rule carries over.
+        const unsigned long long* lst = a.slice_out + ((size_t)n * a.num_slices + lv.first_slice) * kMaxTopk;
+        const int total = lv.num_slices * kMaxTopk;
+        auto key_at = [&](int i) { return (unsigned)(lst[i] >> 32); };  // padding slots carry 0xFFFFFFFF: never selected
+        block_topk(total, k, key_at, cand, hist, wave_cnt, s4);
+        if (tid < k) cand[tid] = lst[(int)(cand[tid] & 0xFFFFFFFFu)];
+        __syncthreads();
+    } else {
+        const int total = lv.H * lv.W * kA;
+        auto key_at = [&](int i) { return ordered_desc(head[(size_t)(i / kA) * a.head_stride + (i % kA)]); };
+        block_topk(total, k, key_at, cand, hist, wave_cnt, s4);
     }
     // ---- decode survivors ----
     if (tid < k) {
@@ -182,7 +228,8 @@ extern "C" int pe_rpn_select_topk(const float* const* level_heads_host, const in
                                   const int32_t* level_stride_host, const float* cell_anchors_host,
                                   int32_t num_levels, int32_t N, int32_t head_stride, int32_t pre_nms_topk,
                                   const int32_t* image_hw, float scale_clamp, float* cand_boxes, float* cand_scores,
-                                  int32_t* cand_level, uint8_t* cand_valid, int32_t cand_per_image, void* stream) {
+                                  int32_t* cand_level, uint8_t* cand_valid, int32_t cand_per_image, void* scratch,
+                                  size_t scratch_bytes, void* stream) {
     PE_CHECK_ARG(num_levels >= 1 && num_levels <= 8, "pe_rpn_select_topk: num_levels %d", num_levels);
     PE_CHECK_ARG(pre_nms_topk >= 1 && pre_nms_topk <= kMaxTopk, "pe_rpn_select_topk: pre_nms_topk %d not in [1,%d]",
                  pre_nms_topk, kMaxTopk);
@@ -209,9 +256,39 @@ extern "C" int pe_rpn_select_topk(const float* const* level_heads_host, const in
     a.num_levels = num_levels; a.N = N; a.head_stride = head_stride; a.image_hw = image_hw;
     a.cand_per_image = cand_per_image; a.scale_clamp = scale_clamp;
     a.cand_boxes = cand_boxes; a.cand_scores = cand_scores; a.cand_level = cand_level; a.cand_valid = cand_valid;
+    // two-stage selection for levels with more than one slice, when the caller provides scratch
+    int ns = 0;
+    for (int l = 0; l < num_levels; ++l) {
+        const int tot = a.lv[l].H * a.lv[l].W * kA;
+        const int cnt = (tot + kSlice - 1) / kSlice;
+        a.lv[l].first_slice = ns;
+        a.lv[l].num_slices = cnt > 1 ? cnt : 0;
+        if (cnt > 1) {
+            for (int c = 0; c < cnt && ns < 64; ++c, ++ns) { a.slice_level[ns] = l; a.slice_begin[ns] = c * kSlice; }
+        }
+    }
+    a.num_slices = ns;
+    const size_t need = (size_t)N * ns * kMaxTopk * sizeof(unsigned long long);
+    if (scratch && ns > 0 && ns < 64 && scratch_bytes >= need) {
+        a.slice_out = (unsigned long long*)scratch;
+        hipLaunchKernelGGL(rpn_slice_kernel, dim3(ns, N), dim3(kThreads), 0, (hipStream_t)stream, a);
+        PE_CHECK_LAUNCH("pe_rpn_select_topk(slices)");
+    } else {
+        a.slice_out = nullptr;
+    }
     hipLaunchKernelGGL(rpn_select_kernel, dim3(num_levels, N), dim3(kThreads), 0, (hipStream_t)stream, a);
     PE_CHECK_LAUNCH("pe_rpn_select_topk");
     return PE_OK;
+}
+
+extern "C" size_t pe_rpn_scratch_bytes(const int32_t* level_hw_host, int32_t num_levels, int32_t N) {
+    size_t ns = 0;
+    for (int l = 0; l < num_levels; ++l) {
+        const long long tot = (long long)level_hw_host[2 * l] * level_hw_host[2 * l + 1] * kA;
+        const long long cnt = (tot + kSlice - 1) / kSlice;
+        if (cnt > 1) ns += (size_t)cnt;
+    }
+    return (size_t)N * ns * kMaxTopk * sizeof(unsigned long long);
 }
 
 extern "C" int pe_gather_boxes(const float* boxes, const float* scores, const int32_t* keep, const int32_t* counts,

@@ -194,9 +194,13 @@ class GeneralizedRCNN:
         cl = torch.empty((N, ncand), dtype=torch.int32, device=dev)
         cv = torch.empty((N, ncand), dtype=torch.uint8, device=dev)
         ptrs = (ctypes.c_void_p * nl)(*[h.data_ptr() for h in heads])
-        st = _lib.lib().pe_rpn_select_topk(ptrs, (ctypes.c_int32 * (2 * nl))(*hw), (ctypes.c_int32 * nl)(*strides[:nl]),
+        hw_c = (ctypes.c_int32 * (2 * nl))(*hw)
+        sbytes = _lib.lib().pe_rpn_scratch_bytes(hw_c, nl, N)
+        scratch = torch.empty((max(sbytes, 8),), dtype=torch.uint8, device=dev)
+        st = _lib.lib().pe_rpn_select_topk(ptrs, hw_c, (ctypes.c_int32 * nl)(*strides[:nl]),
                                           self._cells, nl, N, 16, cfg.pre_nms_topk, _lib.ptr(sizes_dev), SCALE_CLAMP,
-                                          _lib.ptr(cb), _lib.ptr(cs), _lib.ptr(cl), _lib.ptr(cv), ncand, _lib.stream())
+                                          _lib.ptr(cb), _lib.ptr(cs), _lib.ptr(cl), _lib.ptr(cv), ncand,
+                                          _lib.ptr(scratch), sbytes, _lib.stream())
         _lib.check(st, "pe_rpn_select_topk")
         mode = 1 if ncand * 4 > 20000 else 0  # torchvision.batched_nms dispatch (GPU threshold)
         keep, kcnt = L.nms_batched_raw(cb, cs, cl, None, cv, cfg.rpn_nms_thresh, mode, cfg.post_nms_topk)

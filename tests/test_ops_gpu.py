@@ -234,7 +234,8 @@ def test_nms_batched_raw_valid_mask_and_counts(L):
 
 
 # ------------------------------------------------------------------------------------------------ RPN
-def test_rpn_select_matches_oracle():
+@pytest.mark.parametrize("two_stage", [False, True])
+def test_rpn_select_matches_oracle(two_stage):
     import ctypes
     import proben_amd  # noqa: F401
     from oracle import detector as D
@@ -242,7 +243,7 @@ def test_rpn_select_matches_oracle():
     from proben_amd.rcnn import SCALE_CLAMP, cell_anchor_table
     spec = D.DetectorSpec()
     g = torch.Generator().manual_seed(77)
-    N, shapes, strides = 2, [(40, 52), (20, 26), (10, 13), (5, 7), (3, 4)], [4, 8, 16, 32, 64]
+    N, shapes, strides = 2, ([(100, 128), (50, 64), (25, 32), (13, 16), (7, 8)] if two_stage else [(40, 52), (20, 26), (10, 13), (5, 7), (3, 4)]), [4, 8, 16, 32, 64]
     heads, lg_l, dl_l = [], [], []
     for (h, w) in shapes:
         hd = torch.randn(N, h, w, 16, generator=g)
@@ -253,7 +254,7 @@ def test_rpn_select_matches_oracle():
         heads.append(hd)
         lg_l.append(hd[..., :3].permute(0, 3, 1, 2).contiguous())                       # [N, A, H, W]
         dl_l.append(hd[..., 3:15].permute(0, 3, 1, 2).contiguous())                     # [N, 4A, H, W]
-    sizes = [(150, 200), (160, 208)]
+    sizes = [(390, 500), (400, 512)] if two_stage else [(150, 200), (160, 208)]
     want = D.select_proposals(lg_l, dl_l, strides, sizes, spec)
     # --- HIP: selection kernel + NMS + gather
     from proben_amd import layers as L
@@ -266,8 +267,12 @@ def test_rpn_select_matches_oracle():
     hw = (ctypes.c_int32 * 10)(*sum([list(s) for s in shapes], []))
     cells = (ctypes.c_float * 60)(*cell_anchor_table(spec.anchor_sizes, spec.aspect_ratios))
     sz = torch.tensor(sizes, dtype=torch.int32).cuda()
+    sbytes = _lib.lib().pe_rpn_scratch_bytes(hw, 5, N) if two_stage else 0
+    assert (sbytes > 0) == two_stage
+    scratch = torch.empty(max(sbytes, 8), dtype=torch.uint8).cuda()
     st = _lib.lib().pe_rpn_select_topk(ptrs, hw, (ctypes.c_int32 * 5)(*strides), cells, 5, N, 16, 1000, _lib.ptr(sz),
-                                      SCALE_CLAMP, _lib.ptr(cb), _lib.ptr(cs), _lib.ptr(cl), _lib.ptr(cv), ncand, _lib.stream())
+                                      SCALE_CLAMP, _lib.ptr(cb), _lib.ptr(cs), _lib.ptr(cl), _lib.ptr(cv), ncand,
+                                      _lib.ptr(scratch) if two_stage else None, sbytes, _lib.stream())
     _lib.check(st, "rpn")
     keep, cnt = L.nms_batched_raw(cb, cs, cl, None, cv, 0.7, 0, 1000)
     for n in range(N):
