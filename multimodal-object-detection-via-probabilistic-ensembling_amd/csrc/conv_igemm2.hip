@@ -496,7 +496,9 @@ __global__ __launch_bounds__(BM * 2, BM == 128 ? 3 : 4) void conv3x3rb_kernel(Co
     dma_b(0, 0);  // weight tile of the very first tap
     int g = 0;    // running tap counter: tap g uses B stage g & 1
     for (int grp = 0; grp < groups; ++grp) {
-        const int kh = grp / chunks, cc = grp - kh * chunks;
+        // channel chunk OUTER, kernel row INNER: consecutive slabs are the same pixels shifted by one image row, so
+        // the re-read hits the XCD's L2 (LDS-DMA from L2 runs at ~35 TB/s, from MALL/HBM at ~5.5: scripts/lds_dma_probe)
+        const int cc = grp / 3, kh = grp - cc * 3;
         const int c0 = cc * BK;
         // ---- A slab for (kh, chunk); every wave finished reading the previous slab at the barrier below ----
 #pragma unroll
@@ -520,7 +522,7 @@ __global__ __launch_bounds__(BM * 2, BM == 128 ? 3 : 4) void conv3x3rb_kernel(Co
             if (kw < 2) {
                 dma_b((kh * 3 + kw + 1) * a.Cin + c0, (g + 1) & 1);
             } else if (grp + 1 < groups) {
-                const int nkh = (grp + 1) / chunks, ncc = (grp + 1) - nkh * chunks;
+                const int ncc = (grp + 1) / 3, nkh = (grp + 1) - ncc * 3;
                 dma_b((nkh * 3) * a.Cin + ncc * BK, (g + 1) & 1);
             }
             const unsigned char* lbs = lb + (g & 1) * B_BYTES;
