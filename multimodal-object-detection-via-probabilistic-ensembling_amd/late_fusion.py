@@ -116,3 +116,26 @@ def apply_late_fusion_and_evaluate(cfg, evaluator, det_1, det_2, method, det_3="
         evaluator.process([{"file_name": name, "height": H, "width": W, "image_id": iid}], [{"instances": inst}])
     print("Average time:", (time.time() - start) / max(len(det_2["image"]), 1))
     return evaluator.evaluate()
+
+
+def fused_rows_device(fused, image_ids, valid_classes=(0, 1, 2, 5, 7, 16)):
+    """Evaluation rows of one batch ON THE DEVICE: [n,7] float64 = (image_id, x, y, w, h, score, category_id) with the
+    evaluator's class whitelist / remap (FLIR_evaluation.py:313-382) applied - the tensor form that crosses ranks in
+    comm.all_gather_rows (one RCCL all-gather instead of the reference's pickled lists over gloo).
+    `fused`: result of fusion.fuse_detections (or any dict with boxes [B*S,4], scores, classes, counts, offsets, stride)."""
+    B = fused["counts"].numel()
+    S = fused["stride"]
+    dev = fused["scores"].device
+    slot = torch.arange(S, device=dev).unsqueeze(0)                                  # [1,S]
+    live = slot < fused["counts"].unsqueeze(1)                                       # [B,S]
+    cls = fused["classes"].view(B, S).to(torch.int64)
+    ok = torch.zeros_like(live)
+    for c in valid_classes:
+        ok |= cls == c
+    live &= ok
+    cat = torch.where((cls == 5) | (cls == 7), torch.full_like(cls, 2), cls)
+    b = fused["boxes"].view(B, S, 4).double()
+    ids = torch.as_tensor(image_ids, dtype=torch.float64, device=dev).view(B, 1).expand(B, S)
+    rows = torch.stack([ids, b[..., 0], b[..., 1], b[..., 2] - b[..., 0], b[..., 3] - b[..., 1],
+                        fused["scores"].view(B, S).double(), cat.double()], dim=2)
+    return rows[live]                                                               # image-major, score order kept

@@ -172,3 +172,33 @@ def test_kaist_single_class_pipeline():
     for o, n in zip(fused["offsets"].tolist(), c):
         s = fused["scores"][o:o + n]
         assert bool(((s >= 0) & (s <= 1)).all()) and bool((fused["classes"][o:o + n] == 0).all())
+
+
+def test_device_rows_match_host_evaluator_rows():
+    """fused_rows_device == what FLIREvaluator.process builds from Instances (class whitelist, 5/7 -> 2, xywh)."""
+    import proben_amd  # noqa: F401
+    from proben_amd import evaluation, late_fusion as LF
+    from proben_amd.structures import Boxes, Instances
+    g = torch.Generator().manual_seed(3)
+    B, S = 5, 12
+    counts = torch.tensor([12, 0, 7, 3, 9], dtype=torch.int32)
+    boxes = torch.rand(B * S, 4, generator=g, dtype=torch.float64) * 300
+    boxes[:, 2:] += boxes[:, :2] + 1
+    fused = {"boxes": boxes.cuda(), "scores": torch.rand(B * S, generator=g).cuda(),
+             "classes": torch.randint(0, 9, (B * S,), generator=g).float().cuda(), "counts": counts.cuda(),
+             "offsets": (torch.arange(B) * S).int().cuda(), "stride": S}
+    ids = [100, 101, 102, 103, 104]
+    rows = LF.fused_rows_device(fused, ids).cpu().numpy()
+    want = []
+    for b in range(B):
+        c = int(counts[b])
+        inst = Instances((512, 640))
+        inst.pred_boxes = Boxes(boxes[b * S:b * S + c].float())
+        inst.scores = fused["scores"][b * S:b * S + c].cpu()
+        inst.pred_classes = fused["classes"][b * S:b * S + c].cpu()
+        want += evaluation.instances_to_coco_json(inst, ids[b])
+    assert len(rows) == len(want)
+    for r, w in zip(rows, want):
+        assert int(r[0]) == w["image_id"] and int(r[6]) == w["category_id"]
+        np.testing.assert_allclose(r[1:5], w["bbox"], rtol=1e-5, atol=1e-4)   # the host path goes through float32 boxes
+        assert r[5] == pytest.approx(w["score"], rel=1e-6)
