@@ -121,7 +121,8 @@ int pe_set_conv_ablation(int32_t mode);
 /* Kernel-selection policy bits (A/B measurements; default 41 = 1|8|32):
  *   1: 256-row block tiles (8 waves) for 3x3 launches with >= 512 such tiles     2: the same for 1x1 launches
  *   4: two-stage pipeline in the generic 1x1 kernel                              8: 256x256 two-stage kernel for long-K GEMMs
- *  16: 256x256 kernel for every eligible launch                                 32: double-buffered weight tile in the 3x3 kernel */
+ *  16: 256x256 kernel for every eligible launch                                 32: double-buffered weight tile in the 3x3 kernel
+ *  64: experimental 256x256 four-stage ring kernel (counted vmcnt, raw barriers) for every eligible launch */
 int pe_set_conv_tile256(int32_t mode);
 
 /* ---------------------------------------------------------------------------------------------

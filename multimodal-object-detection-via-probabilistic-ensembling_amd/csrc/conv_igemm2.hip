@@ -795,6 +795,233 @@ int launch_big(const Conv2Args& a0, hipStream_t st) {
     return PE_OK;
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Ring-buffered variant: 256 x 256 block tile, 8 waves (2 x 4, each 128 x 64), K-step 32, FOUR 32 KiB LDS stages.
+// Three K-steps of LDS-DMA are in flight while a fourth feeds the MFMAs: a wave waits with a COUNTED
+// `s_waitcnt vmcnt(8)` (its 4 loads of the oldest tile have landed, 8 newer ones stay in flight), then a raw
+// `s_barrier` publishes the tile to the workgroup - `__syncthreads()` would drain the DMA queue (vmcnt(0)).
+// One barrier per K-step; the DMA latency (~1-2 us under load) is covered by three K-steps of MFMAs instead of
+// by co-resident workgroups, so the big tile's 4x flops per L2 byte can actually be used.
+// LDS rows are 64 B: chunk p of row r holds K-chunk p ^ ((r >> 2) & 3) (conflict-free ds_read_b128 for any 16
+// rows distinct mod 16).
+constexpr int RBK = 32, RROW = 64, RSTAGES = 4;
+
+template <int MODE>
+__global__ __launch_bounds__(512, 2) void conv_ring_kernel(Conv2Args a) {
+    constexpr int BM = 256, BN = 256, THREADS = 512;
+    constexpr int WM = 128, WN = 64, TM = 4, TN = 2;
+    constexpr int A_BYTES = BM * RROW;                  // 16 KiB
+    constexpr int STAGE_BYTES = (BM + BN) * RROW;       // 32 KiB
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int nwg = a.tiles_m * a.tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_n = bid % a.tiles_n, tile_m = bid / a.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int lrow = lane >> 2, lp = lane & 3;  // row within the 16-row DMA group, physical 16-B chunk
+
+    // DMA descriptors: every wave owns 2 row groups of A and 2 of B (16 groups of 16 rows each)
+    const _Float16* a_base[2];
+    int a_oh[2], a_ow[2], a_coff[2];
+    bool a_ok[2];
+    const _Float16* b_src[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = (wave * 2 + i) * 16 + lrow;
+        const int m = m0 + r;
+        a_ok[i] = m < a.M;
+        const int mm = a_ok[i] ? m : 0;
+        const int ow = mm % a.Wo, t = mm / a.Wo;
+        const int oh = t % a.Ho, n = t / a.Ho;
+        a_oh[i] = oh * a.stride;
+        a_ow[i] = ow * a.stride;
+        a_base[i] = a.in + (size_t)n * a.H * a.W * a.Cin;
+        a_coff[i] = (lp ^ ((r >> 2) & 3)) * 8;
+        const int nn = n0 + r;
+        b_src[i] = (nn < a.Cout) ? a.wgt + (size_t)nn * a.K + (lp ^ ((r >> 2) & 3)) * 8 : nullptr;
+    }
+    const _Float16* zero = reinterpret_cast<const _Float16*>(g_zero_page);
+
+    float16v acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int frow = lane & 31, fsw = (frow >> 2) & 3, fkh = lane >> 5;
+    const unsigned char* la = smem + (wm * WM + frow) * RROW;
+    const unsigned char* lb = smem + A_BYTES + (wn * WN + frow) * RROW;
+    const int nk = a.K / RBK;
+
+    auto dma = [&](int kt) {
+        const int k0 = kt * RBK;
+        int kh = 0, kw = 0, c0 = k0;
+        if (MODE == MODE_3X3) {
+            const int tap = k0 / a.Cin;
+            c0 = k0 - tap * a.Cin;
+            kh = tap / 3 - 1;
+            kw = tap - (tap / 3) * 3 - 1;
+        }
+        unsigned char* base = smem + (kt & (RSTAGES - 1)) * STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int ih = a_oh[i] + kh, iw = a_ow[i] + kw;
+            bool ok = a_ok[i];
+            if (MODE == MODE_3X3) ok = ok && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+            const _Float16* p = ok ? a_base[i] + ((size_t)ih * a.W + iw) * a.Cin + c0 + a_coff[i] : zero;
+            __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(base + (wave * 2 + i) * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const _Float16* p = b_src[i] ? b_src[i] + k0 : zero;
+            __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(base + A_BYTES + (wave * 2 + i) * 1024), 16, 0, 0);
+        }
+    };
+    // Software pipeline (K-step = 2 MFMA k-slices): the barrier that publishes tile kt+1 sits in the MIDDLE of
+    // K-step kt, so the first fragments of tile kt+1 are fetched from LDS while the last MFMAs of tile kt run -
+    // no LDS read latency is exposed after a barrier.  Fragment registers are double-buffered (F0 / F1).
+    auto load_frags = [&](int stage, int ks, half8 (&af)[TM], half8 (&bf)[TN]) {
+        const unsigned char* pa = la + stage * STAGE_BYTES;
+        const unsigned char* pb = lb + stage * STAGE_BYTES;
+        const int ch = ((ks * 2 + fkh) ^ fsw) << 4;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const half8*>(pa + i * 32 * RROW + ch);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const half8*>(pb + j * 32 * RROW + ch);
+    };
+    auto mfma_all = [&](const half8 (&af)[TM], const half8 (&bf)[TN]) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+    };
+    half8 a0[TM], b0[TN], a1[TM], b1[TN];
+    // prologue: three K-steps in flight; publish tile 0 and fetch its first fragments
+    dma(0);
+    if (nk > 1) dma(1);
+    if (nk > 2) dma(2);
+    if (nk > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    load_frags(0, 0, a0, b0);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int st = kt & (RSTAGES - 1);
+        load_frags(st, 1, a1, b1);
+        mfma_all(a0, b0);
+        if (kt + 1 < nk) {
+            // tile kt+1 landed for this wave once only the (at most one) newer tile is outstanding
+            if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();          // tile kt+1 published; every wave is past tile kt-1
+            if (kt + 3 < nk) dma(kt + 3);          // refill stage (kt-1) & 3
+            load_frags((kt + 1) & (RSTAGES - 1), 0, a0, b0);
+        }
+        mfma_all(a1, b1);
+    }
+    __syncthreads();
+
+    // ---- epilogue: 4 passes of 64 rows (identical to conv_big_kernel) ----
+    constexpr int EP_ROW = BN + 4;
+    constexpr int VEC_PER_ROW = BN / 8;
+    constexpr int NV = 64 * VEC_PER_ROW / THREADS;
+    float* ep = reinterpret_cast<float*>(smem);
+    const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+        half8 rres[NV];
+        if (a.res_mode) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int v = tid + i * THREADS;
+                const int r = v / VEC_PER_ROW, c8 = (v - r * VEC_PER_ROW) * 8;
+                const int m = m0 + pass * 64 + r, c = n0 + c8;
+                rres[i] = zero8;
+                if (m < a.M && c < a.cout_store) {
+                    size_t ro;
+                    if (a.res_mode == 1) {
+                        ro = (size_t)m * a.Cout + c;
+                    } else {
+                        const int ow = m % a.Wo, t = m / a.Wo;
+                        const int oh = t % a.Ho, n = t / a.Ho;
+                        ro = (((size_t)n * a.resH + (oh >> 1)) * a.resW + (ow >> 1)) * a.Cout + c;
+                    }
+                    rres[i] = *reinterpret_cast<const half8*>(a.res + ro);
+                }
+            }
+        }
+        if (wm == (pass >> 1)) {
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int r = ii * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                        const int c = wn * WN + j * 32 + (lane & 31);
+                        ep[r * EP_ROW + c] = acc[2 * (pass & 1) + ii][j][e];
+                    }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int v = tid + i * THREADS;
+            const int r = v / VEC_PER_ROW, c8 = (v - r * VEC_PER_ROW) * 8;
+            const int m = m0 + pass * 64 + r, c = n0 + c8;
+            if (m >= a.M || c >= a.cout_store) continue;
+            const float4v x0 = *reinterpret_cast<const float4v*>(ep + r * EP_ROW + c8);
+            const float4v x1 = *reinterpret_cast<const float4v*>(ep + r * EP_ROW + c8 + 4);
+            float x[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+            if (a.bias) {
+                const float4v b0 = *reinterpret_cast<const float4v*>(a.bias + c);
+                const float4v b1 = *reinterpret_cast<const float4v*>(a.bias + c + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { x[e] += b0[e]; x[e + 4] += b1[e]; }
+            }
+            if (a.res_mode) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] += (float)rres[i][e];
+            }
+            if (a.relu) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] = fmaxf(x[e], 0.f);
+            }
+            half8 h;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) h[e] = (_Float16)x[e];
+            *reinterpret_cast<half8*>(reinterpret_cast<_Float16*>(a.out) + (size_t)m * a.out_stride + c) = h;
+        }
+        __syncthreads();
+    }
+}
+
+template <int MODE>
+int launch_ring(const Conv2Args& a0, hipStream_t st) {
+    Conv2Args a = a0;
+    a.tiles_m = pe::ceil_div(a.M, 256);
+    a.tiles_n = pe::ceil_div(a.Cout, 256);
+    constexpr size_t lds = (size_t)RSTAGES * 512 * RROW;  // 128 KiB
+    static bool done = false;
+    if (!done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_ring_kernel<MODE>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        done = true;
+    }
+    hipLaunchKernelGGL((conv_ring_kernel<MODE>), dim3(a.tiles_m * a.tiles_n), dim3(512), lds, st, a);
+    PE_CHECK_LAUNCH("pe_conv2d_nhwc_f16(256x256 ring)");
+    return PE_OK;
+}
+
 template <int BM, int BN, int MODE, int STAGES = 1>
 int launch2(const Conv2Args& a0, hipStream_t st) {
     Conv2Args a = a0;
@@ -837,6 +1064,10 @@ int conv2_dispatch(const void* in, const void* wgt, const float* bias, const voi
     // 256 x 256 two-stage kernel: fp16 output, whole 256-channel tiles, a grid that fills the 256 CUs
     // (measured r01: +24 % on the K = 12544 FC GEMM, neutral-to-negative on the convolutions -> long-K GEMMs only;
     //  policy bit 4 forces it everywhere it applies, for A/B runs)
+    // experimental (policy bit 6): the 4-stage ring kernel for every eligible launch
+    if ((g_conv_tile256 & 64) && !out_f32 && Cout % 256 == 0 && cout_store == Cout && Cin % 32 == 0 &&
+        (long long)pe::ceil_div(M, 256) * (Cout / 256) >= 224)
+        return mode3x3 ? launch_ring<MODE_3X3>(a, st) : launch_ring<MODE_1X1>(a, st);
     if ((g_conv_tile256 & 8) && !out_f32 && Cout % 256 == 0 && cout_store == Cout &&
         (long long)pe::ceil_div(M, 256) * (Cout / 256) >= 224 && ((g_conv_tile256 & 16) || (!mode3x3 && K >= 4096)))
         return mode3x3 ? launch_big<MODE_3X3>(a, st) : launch_big<MODE_1X1>(a, st);

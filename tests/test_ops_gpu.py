@@ -71,7 +71,8 @@ def test_conv_matches_torch(L, case):
 
 @pytest.mark.parametrize("case", [(8, 100, 128, 128, 256, 3, 1, True, 0), (9, 99, 131, 256, 512, 1, 1, True, 1),
                                   (8, 100, 128, 256, 256, 1, 1, False, 2), (16, 51, 64, 512, 256, 1, 2, False, 0)])
-def test_conv_big_tile_kernel(L, case):
+@pytest.mark.parametrize("policy", [25, 64])
+def test_conv_big_tile_kernel(L, case, policy):
     """The 256x256 two-stage kernel (tile policy bit 3) against torch, incl. ragged M, residual modes, stride 2."""
     import proben_amd
     N, H, W, Cin, Cout, k, s, relu, res_mode = case
@@ -92,7 +93,7 @@ def test_conv_big_tile_kernel(L, case):
         res = nhwc(res)
     if relu:
         ref = ref.relu()
-    lib.pe_set_conv_tile256(25)
+    lib.pe_set_conv_tile256(policy)   # 25: 256x256 two-stage kernel everywhere, 64: 256x256 four-stage ring kernel
     try:
         out = L.conv2d_nhwc(nhwc(x), w.permute(0, 2, 3, 1).contiguous(), b, kernel=k, stride=s, relu=relu, residual=res, residual_mode=res_mode)
         torch.cuda.synchronize()
