@@ -106,3 +106,27 @@ def test_instances_contract():
         assert bool((inst.scores[:-1] >= inst.scores[1:]).all())  # sorted by score
         b = inst.pred_boxes.tensor
         assert float(b[:, 0::2].max()) <= 208 and float(b[:, 1::2].max()) <= 160 and float(b.min()) >= 0
+
+
+def test_r101_full_size_matches_oracle():
+    """BASELINE's architecture and size: R101-FPN on one 800x1000 input (padded 800x1024), 1000 proposals."""
+    want, inter, det, _ = run_pair(101, hw=(840, 1050), n_images=1)  # run_pair crops the last image by 40x50
+    assert tuple(det["_input"][0].shape[1:3]) == (800, 1024) and int(det["proposal_counts"][0]) > 900
+    check_pair(want, inter, det)
+
+
+def test_batch_invariance_full_batch():
+    """Size-independent property at the bench batch (32): every image's result inside the batch equals its
+    batch-1 result (the reference's only mode; its own batch > 1 path mis-indexes logits / variance - quirk Q2)."""
+    import proben_amd  # noqa: F401
+    from proben_amd.rcnn import DetectorConfig, GeneralizedRCNN
+    from proben_amd.synthetic import synthetic_images, synthetic_state_dict
+    model = GeneralizedRCNN(DetectorConfig(), synthetic_state_dict(50, 3, 3, seed=1))
+    frames = torch.from_numpy(synthetic_images(32, 256, 320, seed=11)).cuda()
+    big = model.forward_batch(frames, out_sizes=[(256, 320)] * 32, resize_to=(400, 500))
+    for i in (0, 13, 31):
+        one = model.forward_batch(frames[i:i + 1], out_sizes=[(256, 320)], resize_to=(400, 500))
+        c = int(one["counts"][0])
+        assert c == int(big["counts"][i])
+        for k in ("boxes", "scores", "classes", "class_logits", "prob_score", "vars"):
+            assert torch.equal(one[k][0, :c], big[k][i, :c]), k
