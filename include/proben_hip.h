@@ -148,6 +148,11 @@ int pe_preprocess_pack_batch(const void* src, int32_t num_images, int32_t src_ki
                              void* stream);
 int pe_maxpool3x3s2_nhwc(const void* in, void* out, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
 int pe_subsample2_nhwc(const void* in, void* out, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
+/* Fused BasicStem.forward (modeling/backbone/resnet.py:375-384): conv 7x7 / 2 / pad 3 with the frozen BN folded
+ * + ReLU + max_pool2d(3, 2, 1) in one pass: x [N,H,W,4] fp16 (H, W multiples of 4) -> out [N,H/4,W/4,64] fp16.
+ * w_packed [64,7,8,4] fp16 where tap t multiplies input column 2*c - 4 + t (tap 0 is zero); bias fp32 [64]. */
+int pe_stem_conv7x7_maxpool_f16(const void* x, const void* w_packed, const float* bias, void* out, int32_t N,
+                                int32_t H, int32_t W, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Batched class-aware greedy NMS (float32).  Replaces detectron2.layers.batched_nms

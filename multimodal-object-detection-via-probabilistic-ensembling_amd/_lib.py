@@ -24,6 +24,7 @@ SIGNATURES = {
     "pe_preprocess_pack_batch": [c_void_p] + [c_int] * 12 + [c_void_p] * 4,
     "pe_maxpool3x3s2_nhwc": [c_void_p] * 2 + [c_int] * 4 + [c_void_p],
     "pe_subsample2_nhwc": [c_void_p] * 2 + [c_int] * 4 + [c_void_p],
+    "pe_stem_conv7x7_maxpool_f16": [c_void_p] * 4 + [c_int] * 3 + [c_void_p],
     "pe_nms_scratch_bytes": [c_int, c_int],
     "pe_nms_batched": [c_void_p] * 5 + [c_int, c_int, c_float, c_int, c_int] + [c_void_p] * 3 + [c_size_t, c_void_p],
     "pe_rpn_select_topk": [c_void_p] * 4 + [c_int] * 4 + [c_void_p, c_float] + [c_void_p] * 4 + [c_int, c_void_p, c_size_t, c_void_p],

@@ -196,6 +196,17 @@ def maxpool3x3s2_nhwc(x):
     return out
 
 
+def stem_conv_pool(x, weight_shifted, bias):
+    """Fused BasicStem: conv7x7/2 (+folded BN) + ReLU + max_pool2d(3, 2, 1)  (backbone/resnet.py:375-384).
+    x [N,H,W,4] fp16 (H, W multiples of 4); weight_shifted [64,7,8,4] fp16 with tap 0 zero (weights.pack_stem_fused)."""
+    N, H, W, C = x.shape
+    assert C == 4 and tuple(weight_shifted.shape) == (64, 7, 8, 4) and x.dtype == torch.float16
+    out = torch.empty((N, H // 4, W // 4, 64), dtype=torch.float16, device=x.device)
+    _lib.check(_lib.lib().pe_stem_conv7x7_maxpool_f16(_lib.ptr(x), _lib.ptr(weight_shifted), _lib.ptr(bias), _lib.ptr(out),
+                                                      N, H, W, _lib.stream()), "pe_stem_conv7x7_maxpool_f16")
+    return out
+
+
 def subsample2_nhwc(x):
     N, H, W, C = x.shape
     out = torch.empty((N, (H - 1) // 2 + 1, (W - 1) // 2 + 1, C), dtype=torch.float16, device=x.device)

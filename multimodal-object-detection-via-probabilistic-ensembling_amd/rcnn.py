@@ -89,8 +89,11 @@ class GeneralizedRCNN:
 
     def _bottom_up(self, x, prefix):
         bu = prefix + ".bottom_up"
-        x = self._conv(x, bu + ".stem.conv1", kernel=7, stride=2, relu=True)
-        x = L.maxpool3x3s2_nhwc(x)
+        if (bu + ".stem.fused") in self.w.convs and x.shape[1] % 4 == 0 and x.shape[2] % 4 == 0:
+            x = L.stem_conv_pool(x, *self.w.convs[bu + ".stem.fused"])  # conv + ReLU + pool in one pass over HBM
+        else:
+            x = self._conv(x, bu + ".stem.conv1", kernel=7, stride=2, relu=True)
+            x = L.maxpool3x3s2_nhwc(x)
         outs = []
         for si, nb in enumerate(STAGE_BLOCKS[self.depth]):
             for bi in range(nb):

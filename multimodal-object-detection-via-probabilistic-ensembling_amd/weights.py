@@ -50,6 +50,15 @@ def _pack_stem(w):
     return p.half()
 
 
+def pack_stem_fused(w):
+    """[64, cin<=4, 7, 7] -> [64, 7, 8, 4] for csrc/stem.hip: tap t reads input column 2*c - 4 + t, so the real
+    taps sit at t = 1..7 and t = 0 is a zero weight (keeps every MFMA fragment a 16-byte aligned pixel pair)."""
+    cout, cin = w.shape[0], w.shape[1]
+    p = torch.zeros((cout, 7, 8, 4), dtype=torch.float32)
+    p[:, :, 1:, :cin] = w.permute(0, 2, 3, 1)
+    return p.half()
+
+
 class PackedDetector:
     """Device-resident packed weights of one detector."""
 
@@ -99,6 +108,8 @@ class PackedDetector:
         bu = prefix + ".bottom_up"
         w, b = _fold(sd, bu + ".stem.conv1")
         self.convs[bu + ".stem.conv1"] = (_pack_stem(w).to(dev), b.to(dev))
+        if w.shape[0] == 64 and w.shape[1] <= 4:  # every reference config (STEM_OUT_CHANNELS 64)
+            self.convs[bu + ".stem.fused"] = (pack_stem_fused(w).to(dev), b.to(dev))
         for si, nb in enumerate(STAGE_BLOCKS[self.depth]):
             for bi in range(nb):
                 for c in ("conv1", "conv2", "conv3", "shortcut"):

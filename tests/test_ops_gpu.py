@@ -151,6 +151,28 @@ def test_stem_matches_torch(L, cin):
     torch.testing.assert_close(out.permute(0, 3, 1, 2).float(), ref, rtol=4e-3, atol=4e-3)
 
 
+@pytest.mark.parametrize("cin,hw", [(3, (96, 128)), (4, (64, 96)), (3, (36, 44)), (3, (800, 1024))])
+def test_fused_stem_pool_matches_torch(L, cin, hw):
+    """conv7x7/2 + ReLU + max_pool2d(3,2,1) in one kernel (csrc/stem.hip) vs torch fp32 on the fp16-rounded
+    operands; sizes cover ragged pooled tiles (Hp % 4 != 0, Wp % 16 != 0) and BASELINE's 800 x 1024."""
+    import proben_amd.weights as WT
+    g = torch.Generator().manual_seed(3)
+    n = 2
+    x = torch.randn(n, cin, *hw, generator=g)
+    w = torch.randn(64, cin, 7, 7, generator=g) / (cin * 49) ** 0.5
+    b = torch.randn(64, generator=g)
+    x4 = torch.zeros(n, *hw, 4)
+    x4[..., :cin] = x.permute(0, 2, 3, 1)
+    got = L.stem_conv_pool(x4.cuda().half(), WT.pack_stem_fused(w).cuda(), b.cuda())
+    conv = torch.nn.functional.conv2d(x.cuda().half().float(), w.cuda().half().float(), b.cuda(), stride=2, padding=3).relu()
+    ref = torch.nn.functional.max_pool2d(conv.half().float(), 3, 2, 1)
+    assert got.shape == (n, hw[0] // 4, hw[1] // 4, 64)
+    torch.testing.assert_close(got.permute(0, 3, 1, 2).float(), ref, rtol=4e-3, atol=4e-3)
+    # and against the unfused HIP kernels (same fp16 rounding points; accumulation order differs)
+    un = L.maxpool3x3s2_nhwc(L.conv2d_nhwc(x4.cuda().half(), WT._pack_stem(w).cuda(), b.cuda(), kernel=7, stride=2, relu=True))
+    torch.testing.assert_close(got.float(), un.float(), rtol=2e-3, atol=2e-3)
+
+
 def test_linear_matches_torch(L):
     g = torch.Generator().manual_seed(5)
     x = torch.randn(333, 12544, generator=g).cuda().half()
