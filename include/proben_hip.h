@@ -242,6 +242,25 @@ int pe_boxhead_finalize(const float* head, int32_t head_stride, int32_t N, int32
                         float* det_probs, float* det_vars, int32_t* det_rows, int32_t* det_counts,
                         void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Native COCO bbox evaluator (HOST code, multithreaded; no GPU involved).  Replaces COCOeval.evaluate /
+ * computeIoU / evaluateImg / accumulate of the reference's vendored pycocotools
+ * (detectron2/pycocotools/cocoeval.py:85-191, 236-421, Params :500-536) and pycocotools 2.0.4 `_mask.iou`
+ * (bbIou) for iouType "bbox"; caller: FLIR_evaluation.py:496-563 (_evaluate_predictions_on_coco).
+ *   Ground truth rows (annotation order): gt_img / gt_cat = DENSE indices into the sorted image-id / category-id
+ *   lists, gt_box [n_gt,4] xywh float64, gt_area, gt_crowd (uint8), gt_id (annotation ids; an id of 0 counts
+ *   as "unmatched", like the reference).  Detection rows (result order; detection id = row + 1, area = w*h):
+ *   dt_img, dt_cat, dt_box [n_dt,4] xywh, dt_score.
+ *   iou_thrs [T], rec_thrs [R], max_dets [M] ascending, area_rng [A,2].  num_threads <= 0: hardware concurrency (<= 32).
+ *   Out: precision [T,R,K,A,M] and recall [T,K,A,M] float64, -1 where the reference leaves -1.
+ * ------------------------------------------------------------------------------------------- */
+int pe_cocoeval_bbox(const int32_t* gt_img, const int32_t* gt_cat, const double* gt_box, const double* gt_area,
+                     const uint8_t* gt_crowd, const int64_t* gt_id, int64_t n_gt, const int32_t* dt_img,
+                     const int32_t* dt_cat, const double* dt_box, const double* dt_score, int64_t n_dt,
+                     int32_t n_imgs, int32_t n_cats, const double* iou_thrs, int32_t T, const double* rec_thrs,
+                     int32_t R, const int32_t* max_dets, int32_t M, const double* area_rng, int32_t A,
+                     int32_t num_threads, double* precision, double* recall);
+
 #ifdef __cplusplus
 }
 #endif

@@ -212,7 +212,7 @@ extern "C" int pe_nms_batched(const float* boxes, const float* scores, const int
     PE_CHECK_ARG(max_out >= 1, "pe_nms_batched: max_out < 1");
     hipStream_t st = (hipStream_t)stream;
     if (n_max == 0) {
-        hipMemsetAsync(out_counts, 0, sizeof(int32_t) * B, st);
+        (void)hipMemsetAsync(out_counts, 0, sizeof(int32_t) * B, st);
         return PE_OK;
     }
     PE_CHECK_ARG(boxes && scores && scratch, "pe_nms_batched: null pointer");

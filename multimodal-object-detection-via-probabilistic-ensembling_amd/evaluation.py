@@ -48,7 +48,13 @@ class COCOevalBBox:
     """gt_json: a COCO dataset dict ("images", "annotations", "categories"); results: list of
     {"image_id", "category_id", "bbox" [x,y,w,h], "score"}."""
 
-    def __init__(self, gt_json, results):
+    def __init__(self, gt_json, results, impl="native", num_threads=0):
+        """impl "native": evaluate + accumulate run in libproben_hip.so's multithreaded host evaluator
+        (csrc/cocoeval.cpp, pe_cocoeval_bbox); "numpy": the NumPy restatement below (bit-identical results,
+        ~1000x slower; it is the form pinned to the reference by tests/golden/cocoeval_case.json)."""
+        assert impl in ("native", "numpy"), impl
+        self.impl, self.num_threads = impl, num_threads
+        self._gt_json, self._results = gt_json, results
         self.iou_thrs = np.linspace(.5, 0.95, int(np.round((0.95 - .5) / .05)) + 1, endpoint=True)
         self.rec_thrs = np.linspace(.0, 1.00, int(np.round((1.00 - .0) / .01)) + 1, endpoint=True)
         self.max_dets = [1, 10, 100]
@@ -113,9 +119,46 @@ class COCOevalBBox:
         return out
 
     def evaluate(self):
+        if self.impl == "native":
+            self._per = None  # matching happens inside pe_cocoeval_bbox (accumulate)
+            return
         self._per = {(i, c): self._eval_img(i, c) for c in self.cat_ids for i in self.img_ids}
 
+    def _accumulate_native(self):
+        import ctypes
+        from . import _lib
+        T, R, K, A, M = len(self.iou_thrs), len(self.rec_thrs), len(self.cat_ids), len(self.area_rng), len(self.max_dets)
+        img_ix = {v: i for i, v in enumerate(self.img_ids)}
+        cat_ix = {v: i for i, v in enumerate(self.cat_ids)}
+        anns = [a for a in self._gt_json.get("annotations", []) if a["category_id"] in cat_ix and a["image_id"] in img_ix]
+        res = [r for r in self._results if r["category_id"] in cat_ix]  # other categories are never looked up
+        gt_img = np.array([img_ix[a["image_id"]] for a in anns], dtype=np.int32)
+        gt_cat = np.array([cat_ix[a["category_id"]] for a in anns], dtype=np.int32)
+        gt_box = np.array([a["bbox"] for a in anns], dtype=np.float64).reshape(-1, 4)
+        gt_area = np.array([a.get("area", a["bbox"][2] * a["bbox"][3]) for a in anns], dtype=np.float64)
+        gt_crowd = np.array([int(a.get("iscrowd", 0)) != 0 for a in anns], dtype=np.uint8)
+        gt_id = np.array([a["id"] for a in anns], dtype=np.int64)
+        dt_img = np.array([img_ix[r["image_id"]] for r in res], dtype=np.int32)
+        dt_cat = np.array([cat_ix[r["category_id"]] for r in res], dtype=np.int32)
+        dt_box = np.array([r["bbox"] for r in res], dtype=np.float64).reshape(-1, 4)
+        dt_score = np.array([r["score"] for r in res], dtype=np.float64)
+        precision = np.empty((T, R, K, A, M), dtype=np.float64)
+        recall = np.empty((T, K, A, M), dtype=np.float64)
+        iou = np.ascontiguousarray(self.iou_thrs, dtype=np.float64)
+        rec = np.ascontiguousarray(self.rec_thrs, dtype=np.float64)
+        md = np.array(self.max_dets, dtype=np.int32)
+        ar = np.array(self.area_rng, dtype=np.float64)
+        p = lambda a: a.ctypes.data_as(ctypes.c_void_p) if a.size else None
+        st = _lib.lib().pe_cocoeval_bbox(p(gt_img), p(gt_cat), p(gt_box), p(gt_area), p(gt_crowd), p(gt_id), len(anns),
+                                         p(dt_img), p(dt_cat), p(dt_box), p(dt_score), len(res), len(self.img_ids), K,
+                                         p(iou), T, p(rec), R, p(md), M, p(ar), A, int(self.num_threads), p(precision),
+                                         p(recall))
+        _lib.check(st, "pe_cocoeval_bbox")
+        self.eval = {"precision": precision, "recall": recall, "counts": [T, R, K, A, M]}
+
     def accumulate(self):
+        if self.impl == "native":
+            return self._accumulate_native()
         T, R, K, A, M = len(self.iou_thrs), len(self.rec_thrs), len(self.cat_ids), len(self.area_rng), len(self.max_dets)
         precision = -np.ones((T, R, K, A, M))
         recall = -np.ones((T, K, A, M))

@@ -13,9 +13,12 @@ from proben_amd.cli import demo_LAMR_KAIST
 from proben_amd.structures import Boxes, ImageList, Instances
 
 
-def test_cocoeval_matches_reference_vendored_evaluator(golden_dir):
+@pytest.mark.parametrize("impl", ["native", "numpy"])
+def test_cocoeval_matches_reference_vendored_evaluator(golden_dir, impl):
+    """Both evaluators (the multithreaded C++ one in libproben_hip.so and its NumPy restatement) against the
+    fixture produced by the reference's vendored COCOeval (tests/golden/gen_cocoeval.py)."""
     z = json.load(open(os.path.join(golden_dir, "cocoeval_case.json")))
-    ev = evaluation.COCOevalBBox(z["gt"], z["dets"])
+    ev = evaluation.COCOevalBBox(z["gt"], z["dets"], impl=impl)
     ev.evaluate()
     ev.accumulate()
     stats = ev.summarize(printer=None)
@@ -28,6 +31,57 @@ def test_cocoeval_matches_reference_vendored_evaluator(golden_dir):
         p = prec[:, :, k, 0, -1]
         p = p[p > -1]
         assert float(np.mean(p)) == pytest.approx(want, abs=1e-12)
+
+
+def _random_eval_case(n_images, seed, crowd):
+    rng = np.random.default_rng(seed)
+    images = [{"id": 10 + 3 * i, "height": 512, "width": 640} for i in range(n_images)]
+    anns, res = [], []
+    for im in images:
+        for _ in range(rng.integers(0, 12)):
+            x, y = rng.uniform(0, 500), rng.uniform(0, 400)
+            w, h = rng.uniform(4, 200, 2)
+            c = int(rng.integers(1, 4))
+            anns.append({"id": len(anns), "image_id": im["id"], "category_id": c, "bbox": [x, y, w, h], "area": w * h,
+                         "iscrowd": int(crowd and rng.random() < .15)})   # ids start at 0: id 0 = "unmatched" quirk
+            for _ in range(rng.integers(0, 3)):
+                res.append({"image_id": im["id"], "category_id": c, "score": float(np.round(rng.uniform(.5, 1), 2)),
+                            "bbox": [x + rng.normal(0, 4), y + rng.normal(0, 4), w * rng.uniform(.8, 1.2), h]})
+        for _ in range(rng.integers(0, 8)):   # category 4 has no ground truth; 5 is not a dataset category
+            x, y = rng.uniform(0, 500), rng.uniform(0, 400)
+            w, h = rng.uniform(4, 200, 2)
+            res.append({"image_id": im["id"], "category_id": int(rng.integers(1, 6)), "bbox": [x, y, w, h],
+                        "score": float(np.round(rng.uniform(.5, 1), 2))})
+    return {"images": images, "annotations": anns, "categories": [{"id": c} for c in (1, 2, 3, 4)]}, res
+
+
+@pytest.mark.parametrize("n_images,seed,crowd,threads", [(1, 0, False, 1), (40, 1, False, 3), (150, 2, True, 0)])
+def test_native_cocoeval_bit_identical_to_numpy(n_images, seed, crowd, threads):
+    """Tied scores (rounded to 0.01), crowd boxes, >100 detections in one cell, empty cells, a category without
+    ground truth, annotation id 0: precision / recall tables must be equal bit for bit."""
+    gt, res = _random_eval_case(n_images, seed, crowd)
+    if n_images == 40:  # one (image, category) cell above maxDets = 100
+        res += [{"image_id": 10, "category_id": 1, "bbox": [5.0 * k, 3.0 * k, 40, 40], "score": 0.5 + (k % 50) / 100}
+                for k in range(130)]
+    a = evaluation.COCOevalBBox(gt, res, impl="numpy")
+    b = evaluation.COCOevalBBox(gt, res, impl="native", num_threads=threads)
+    for e in (a, b):
+        e.evaluate()
+        e.accumulate()
+        e.summarize(printer=None)
+    assert np.array_equal(a.eval["precision"], b.eval["precision"])
+    assert np.array_equal(a.eval["recall"], b.eval["recall"])
+    assert np.array_equal(a.stats, b.stats)
+
+
+def test_native_cocoeval_empty_and_bad_rows():
+    gt = {"images": [{"id": 1}], "annotations": [], "categories": [{"id": 1}]}
+    e = evaluation.COCOevalBBox(gt, [])
+    e.evaluate()
+    e.accumulate()
+    assert (e.eval["precision"] == -1).all() and (e.summarize(printer=None) == -1).all()
+    with pytest.raises(AssertionError):   # the reference's loadRes assertion
+        evaluation.COCOevalBBox(gt, [{"image_id": 7, "category_id": 1, "bbox": [0, 0, 1, 1], "score": .5}])
 
 
 def test_flir_evaluator_end_to_end(tmp_path, golden_dir):
