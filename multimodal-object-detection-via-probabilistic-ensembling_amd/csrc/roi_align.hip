@@ -9,8 +9,9 @@
 // The reference's CUDA kernel is one thread per output element over NCHW (uncoalesced).  Here features are
 // NHWC: one block per ROI, a thread owns a vector of VEC consecutive channels of one output bin, so every
 // bilinear tap is a coalesced 16-byte (fp16 x8) / 16-byte (fp32 x4) load shared by a wavefront's lanes.
-// Per sample the 4 taps are combined in the reference's order (w1*v1 + w2*v2 + w3*v3 + w4*v4, then
-// accumulated, then divided by the sample count) so fp32 results are bit-identical to the CPU kernel.
+// fp32 features: per sample the 4 taps are combined in the reference's order (w1*v1 + w2*v2 + w3*v3 + w4*v4, then
+// accumulated, then divided by the sample count) so results are bit-identical to the CPU kernel.
+// fp16 features (the detector's path): separable, table-driven form below.
 // Output layout: [R, ph, pw, C] (the box head's fc1 weight is permuted to match at load time).
 #include <hip/hip_fp16.h>
 
@@ -68,20 +69,48 @@ struct Vec<float> {
     }
 };
 
-// weight of integer row/column `r` accumulated over the `grid` sample positions start + (i+.5)*bin/grid of one bin,
-// with the reference's validity window [-1, size], clamps and bilinear split (ROIAlign_cpu.cpp:43-96)
-__device__ __forceinline__ float axis_weight(int r, float start, float bin, int grid, int size) {
-    float w = 0.f;
-    for (int i = 0; i < grid; ++i) {
-        float y = start + (float)(i + .5f) * bin / (float)grid;
-        if (y < -1.0f || y > (float)size) continue;
-        if (y <= 0) y = 0;
-        int lo = (int)y, hi;
-        if (lo >= size - 1) { hi = lo = size - 1; y = (float)lo; } else hi = lo + 1;
-        const float l = y - lo, h = 1.f - l;
-        w += (lo == r ? h : 0.f) + (hi == r ? l : 0.f);
+// Separable form, table driven (fp16 features): the sample grid of a bin is a tensor product, so
+//   sum_iy sum_ix bilinear(y_iy, x_ix) = sum_r Wy[r] * sum_c Wx[c] * f(r, c)
+// with at most (grid_h + 1) x (grid_w + 1) pixel loads per bin instead of 4 * grid_h * grid_w taps (9 vs 16 at
+// grid 2, 25 vs 64 at grid 4).  One thread per (axis, bin) folds the reference's per-sample rules (validity window
+// [-1, size], clamps, bilinear split: ROIAlign_cpu.cpp:43-96) into a short weight row in LDS ONCE per ROI; the
+// 256 threads then only do load + 8 fused multiply-adds per pixel (the tap form spends ~100 VALU instructions per
+// sample on coordinates and fp16 -> fp32 converts, which made it VALU-issue bound).  Summation order differs
+// from the reference kernel, which is why fp32 features keep the tap form (bit-exact).
+constexpr int SEP_MAXB = 8;    // pooled bins per axis
+constexpr int SEP_MAXN = 20;   // pixels per bin per axis (grid <= ~18); larger ROIs fall back to the tap form
+
+struct SepTables {
+    float w[2][SEP_MAXB][SEP_MAXN];
+    int first[2][SEP_MAXB], n[2][SEP_MAXB];
+    int fallback;
+};
+
+__device__ void sep_build_axis(SepTables& t, int axis, int bin, float start, float bin_size, int grid, int size) {
+    int lo_min = 0x7fffffff, hi_max = -1;
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass == 1) {
+            if (hi_max < 0) { t.n[axis][bin] = 0; t.first[axis][bin] = 0; return; }
+            const int n = hi_max - lo_min + 1;
+            if (n > SEP_MAXN) { t.fallback = 1; t.n[axis][bin] = 0; return; }
+            t.n[axis][bin] = n; t.first[axis][bin] = lo_min;
+            for (int i = 0; i < n; ++i) t.w[axis][bin][i] = 0.f;
+        }
+        for (int i = 0; i < grid; ++i) {
+            float y = start + (float)(i + .5f) * bin_size / (float)grid;
+            if (y < -1.0f || y > (float)size) continue;
+            if (y <= 0) y = 0;
+            int lo = (int)y, hi;
+            if (lo >= size - 1) { hi = lo = size - 1; y = (float)lo; } else hi = lo + 1;
+            if (pass == 0) {
+                lo_min = min(lo_min, lo); hi_max = max(hi_max, hi);
+            } else {
+                const float l = y - lo, h = 1.f - l;
+                t.w[axis][bin][lo - lo_min] += h;
+                t.w[axis][bin][hi - lo_min] += l;
+            }
+        }
     }
-    return w;
 }
 
 template <typename T, bool SEP>
@@ -125,36 +154,44 @@ __global__ __launch_bounds__(256) void roi_align_kernel(RoiArgs a) {
     const int cvec = a.C / V;
     const int items = a.ph * a.pw * cvec;
     T* out = reinterpret_cast<T*>(a.out) + (size_t)r * a.ph * a.pw * a.C;
+    __shared__ SepTables tabs;
+    if (SEP) {
+        if (threadIdx.x == 0) tabs.fallback = (a.ph > SEP_MAXB || a.pw > SEP_MAXB) ? 1 : 0;
+        __syncthreads();
+        if (live && !tabs.fallback) {
+            const int t = threadIdx.x;
+            if (t < a.ph) sep_build_axis(tabs, 0, t, start_h + t * bin_h, bin_h, grid_h, H);
+            else if (t < a.ph + a.pw) sep_build_axis(tabs, 1, t - a.ph, start_w + (t - a.ph) * bin_w, bin_w, grid_w, W);
+        }
+        __syncthreads();
+    }
     for (int it = threadIdx.x; it < items; it += blockDim.x) {
         const int cv = it % cvec, bin = it / cvec;
         const int ph = bin / a.pw, pw = bin - ph * a.pw;
         float acc[V];
 #pragma unroll
         for (int e = 0; e < V; ++e) acc[e] = 0.f;
-        if (live && SEP) {
-            // Separable form (NOT dispatched: measured 1.9x SLOWER than the tap form on MI355X, r01 - the per-row /
-            // per-column weight loops cost more VALU than the saved L2 hits; kept for the record):
-            // the sample grid is a tensor product, so
-            //   sum_iy sum_ix bilinear(y_iy, x_ix) = sum_r Wy[r] sum_c Wx[c] f(r, c)
-            // with (grid+1)^2 pixel loads per bin instead of 4*grid^2 taps (16 vs 36 at grid 3).  Summation
-            // order differs from the reference kernel (fp32 mode keeps the reference order below).
-            const float ys = start_h + ph * bin_h, xs = start_w + pw * bin_w;
-            const float y_first = ys + 0.5f * bin_h / (float)grid_h, y_last = ys + ((float)grid_h - 0.5f) * bin_h / (float)grid_h;
-            const float x_first = xs + 0.5f * bin_w / (float)grid_w, x_last = xs + ((float)grid_w - 0.5f) * bin_w / (float)grid_w;
-            const int r0 = max(0, min(H - 1, (int)floorf(y_first))), r1 = max(0, min(H - 1, (int)floorf(y_last) + 1));
-            const int c0 = max(0, min(W - 1, (int)floorf(x_first))), c1 = max(0, min(W - 1, (int)floorf(x_last) + 1));
-            for (int r = r0; r <= r1; ++r) {
-                const float wy = axis_weight(r, ys, bin_h, grid_h, H);
-                if (wy == 0.f) continue;
-                for (int c = c0; c <= c1; ++c) {
-                    const float wx = axis_weight(c, xs, bin_w, grid_w, W);
-                    if (wx == 0.f) continue;
-                    float v[V];
-                    Vec<T>::load(feat + ((size_t)r * W + c) * a.C + cv * V, v);
-                    const float w = wy * wx;
+        if (live && SEP && !tabs.fallback) {
+            const int ny = tabs.n[0][ph], nx = tabs.n[1][pw];
+            const int npx = ny * nx;
+            const T* base = feat + ((size_t)tabs.first[0][ph] * W + tabs.first[1][pw]) * a.C + cv * V;
+            const float* wyr = tabs.w[0][ph];
+            const float* wxr = tabs.w[1][pw];
+            int rr = 0, c = 0;
+            for (int i = 0; i < npx; i += 4) {  // 4 independent 16-byte loads in flight per lane
+                half8 h[4];
+                float w[4];
 #pragma unroll
-                    for (int e = 0; e < V; ++e) acc[e] += w * v[e];
+                for (int u = 0; u < 4; ++u) {
+                    const bool ok = i + u < npx;
+                    w[u] = ok ? wyr[rr] * wxr[c] : 0.f;
+                    h[u] = *reinterpret_cast<const half8*>(base + ((size_t)rr * W + c) * a.C);
+                    if (i + u + 1 < npx && ++c == nx) { c = 0; ++rr; }   // stays on the last pixel past the end
                 }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int e = 0; e < V; ++e) acc[e] = __builtin_fmaf((float)h[u][e], w[u], acc[e]);
             }
 #pragma unroll
             for (int e = 0; e < V; ++e) acc[e] /= count;
@@ -214,8 +251,13 @@ extern "C" int pe_roi_align_nhwc(const void* const* feats_host, const int32_t* f
     a.min_level = 2; a.max_level = 5; a.canonical_level = 4; a.canonical_size = 224.f;
     a.out = output; a.out_level = out_level;
     // (tried in r01 and dropped: a wave-per-bin variant with scalar sample math and 8-byte lanes: 1.61 vs 1.47 ms)
-    if (dtype == 0)
-        hipLaunchKernelGGL((roi_align_kernel<_Float16, false>), dim3(num_rois), dim3(256), 0, (hipStream_t)stream, a);
+    if (dtype == 0) {
+        // one pooled row per pass when it fits (C = 256: 7 bins x 32 lanes = 224 threads, 7 full passes instead of
+        // 6 full + 1 one-eighth-full pass of 256)
+        const int row_threads = (C / 8) * pooled_w;
+        const int threads = row_threads <= 256 ? row_threads : 256;
+        hipLaunchKernelGGL((roi_align_kernel<_Float16, true>), dim3(num_rois), dim3(threads), 0, (hipStream_t)stream, a);
+    }
     else
         hipLaunchKernelGGL((roi_align_kernel<float, false>), dim3(num_rois), dim3(256), 0, (hipStream_t)stream, a);
     PE_CHECK_LAUNCH("pe_roi_align_nhwc");
