@@ -115,14 +115,16 @@ int pe_conv2d_nhwc_f16(const void* input, const void* weight, const float* bias,
  * 2 (default) = LDS-DMA (global_load_lds) kernels incl. the kw-reuse 3x3 kernel, 3 = LDS-DMA kernels with the
  * generic (per-tap) 3x3.  The 7x7 stem always uses 1.  Process-global. */
 int pe_set_conv_impl(int32_t impl);
-/* Measurement aid (results become WRONG): 0 = normal, 1 = skip the LDS-DMA loads, 2 = skip the MFMAs of the
- * kw-reuse 3x3 kernel.  Used by scripts/ablate_conv.py only. */
+/* Measurement aid (results become WRONG): 0 = normal, 1 = skip the LDS-DMA loads, 2 = skip the MFMAs (kw-reuse 3x3
+ * kernel and phase-split kernel), 3 = skip the fragment reads (phase-split kernel); bits 4-5 choose the phase-split
+ * kernel's stagger partition.  Used by scripts/ablate_conv.py / scripts/ablate_p8.py only. */
 int pe_set_conv_ablation(int32_t mode);
 /* Kernel-selection policy bits (A/B measurements; default 41 = 1|8|32):
  *   1: 256-row block tiles (8 waves) for 3x3 launches with >= 512 such tiles     2: the same for 1x1 launches
  *   4: two-stage pipeline in the generic 1x1 kernel                              8: 256x256 two-stage kernel for long-K GEMMs
  *  16: 256x256 kernel for every eligible launch                                 32: double-buffered weight tile in the 3x3 kernel
- *  64: experimental 256x256 four-stage ring kernel (counted vmcnt, raw barriers) for every eligible launch */
+ *  64: experimental 256x256 four-stage ring kernel (counted vmcnt, raw barriers) for every eligible launch
+ * 128: experimental 256x256 phase-split kernel (quadrant phases, staggered wave rows, s_setprio) for every eligible launch */
 int pe_set_conv_tile256(int32_t mode);
 
 /* ---------------------------------------------------------------------------------------------

@@ -70,8 +70,9 @@ def test_conv_matches_torch(L, case):
 
 
 @pytest.mark.parametrize("case", [(8, 100, 128, 128, 256, 3, 1, True, 0), (9, 99, 131, 256, 512, 1, 1, True, 1),
-                                  (8, 100, 128, 256, 256, 1, 1, False, 2), (16, 51, 64, 512, 256, 1, 2, False, 0)])
-@pytest.mark.parametrize("policy", [25, 64])
+                                  (8, 100, 128, 256, 256, 1, 1, False, 2), (16, 51, 64, 512, 256, 1, 2, False, 0),
+                                  (8, 100, 128, 64, 256, 1, 1, True, 0), (8, 100, 128, 128, 256, 1, 1, False, 1)])
+@pytest.mark.parametrize("policy", [25, 64, 128])
 def test_conv_big_tile_kernel(L, case, policy):
     """The 256x256 two-stage kernel (tile policy bit 3) against torch, incl. ragged M, residual modes, stride 2."""
     import proben_amd
@@ -93,7 +94,8 @@ def test_conv_big_tile_kernel(L, case, policy):
         res = nhwc(res)
     if relu:
         ref = ref.relu()
-    lib.pe_set_conv_tile256(policy)   # 25: 256x256 two-stage kernel everywhere, 64: 256x256 four-stage ring kernel
+    # 25: 256x256 two-stage kernel everywhere, 64: 256x256 four-stage ring kernel, 128: 256x256 phase-split kernel
+    lib.pe_set_conv_tile256(policy)
     try:
         out = L.conv2d_nhwc(nhwc(x), w.permute(0, 2, 3, 1).contiguous(), b, kernel=k, stride=s, relu=relu, residual=res, residual_mode=res_mode)
         torch.cuda.synchronize()
