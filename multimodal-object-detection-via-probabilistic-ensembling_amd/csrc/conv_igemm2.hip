@@ -426,6 +426,7 @@ __global__ __launch_bounds__(BM * 2, BM == 128 ? 3 : 4) void conv3x3r_kernel(Con
 // instead of 6.  LDS: slab + 2 x 16 KiB (66 KiB at BM = 256: still two 8-wave workgroups per CU).
 template <int BM, int BN>
 __global__ __launch_bounds__(BM * 2, BM == 128 ? 3 : 4) void conv3x3rb_kernel(Conv2Args a) {
+    static_assert(BM <= 512, "at most 16 waves");
     constexpr int ABL = 0;
     constexpr int THREADS = BM * 2, WAVES = BM / 32;   // waves as (BM/64) x 2, each 64 x (BN/2)
     constexpr int WM = 64, WN = BN / 2;
@@ -1309,6 +1310,9 @@ int conv2_dispatch(const void* in, const void* wgt, const float* bias, const voi
         if (narrow) return launch3x3r<128, 64>(a, st);
         // 256-row tiles (8 waves) halve the weight-tile traffic per flop; keep 128 when the grid would not fill the chip
         const bool big = (g_conv_tile256 & 1) && (long long)pe::ceil_div(M, 256) * pe::ceil_div(Cout, 128) >= 512;
+        // experimental (policy bit 8): 512-row / 16-wave tiles - one workgroup per CU shares ONE weight tile per tap
+        if ((g_conv_tile256 & 256) && (g_conv_tile256 & 32) && (long long)pe::ceil_div(M, 512) * pe::ceil_div(Cout, 128) >= 512)
+            return launch3x3r<512, 128>(a, st);
         return big ? launch3x3r<256, 128>(a, st) : launch3x3r<128, 128>(a, st);
     }
     if (mode3x3) return narrow ? launch2<128, 64, MODE_3X3>(a, st) : launch2<128, 128, MODE_3X3>(a, st);

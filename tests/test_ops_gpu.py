@@ -105,11 +105,12 @@ def test_conv_big_tile_kernel(L, case, policy):
 
 
 @pytest.mark.parametrize("case", [(16, 100, 128, 128, 128, 3, 1, True, 0), (9, 99, 131, 64, 256, 3, 1, False, 0),
-                                  (2, 25, 32, 256, 256, 3, 1, True, 0), (3, 40, 50, 64, 64, 3, 1, True, 0)])
+                                  (2, 25, 32, 256, 256, 3, 1, True, 0), (3, 40, 50, 64, 64, 3, 1, True, 0),
+                                  (16, 101, 127, 128, 256, 3, 1, True, 512)])
 def test_conv3x3_weight_double_buffered_kernel(L, case):
     """The kw-reuse 3x3 kernel with the double-buffered weight tile (tile policy bit 5), 128- and 256-row tiles."""
     import proben_amd
-    N, H, W, Cin, Cout, k, s, relu, _ = case
+    N, H, W, Cin, Cout, k, s, relu, rows = case   # rows = 512: the experimental 512-row / 16-wave tile (policy bit 8)
     lib = proben_amd._lib.lib()
     g = torch.Generator(device="cpu").manual_seed(13)
     x = torch.randn(N, Cin, H, W, generator=g).cuda().half()
@@ -118,7 +119,7 @@ def test_conv3x3_weight_double_buffered_kernel(L, case):
     ref = torch.nn.functional.conv2d(x.float(), w.float(), b, stride=s, padding=1)
     if relu:
         ref = ref.relu()
-    lib.pe_set_conv_tile256(9 | 32)
+    lib.pe_set_conv_tile256(9 | 32 | (256 if rows == 512 else 0))
     try:
         out = L.conv2d_nhwc(nhwc(x), w.permute(0, 2, 3, 1).contiguous(), b, kernel=k, stride=s, relu=relu)
         torch.cuda.synchronize()
