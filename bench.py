@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--conv-impl", type=int, default=2, help="1: register-staged conv kernel, 2: LDS-DMA conv kernel")
     ap.add_argument("--serial-detectors", action="store_true", help="run the two detectors back to back on one stream")
+    ap.add_argument("--stagger", type=int, default=0, help="N > 0: throughput mode, detector 2 trails detector 1 by its res<N> stage")
     ap.add_argument("--tile256", type=int, default=-1, help="conv tile policy override (pe_set_conv_tile256)")
     ap.add_argument("--layers", type=str, default="", help="write a per-conv-launch table (shape, ms, TFLOP/s) to this file")
     return ap.parse_args()
@@ -56,18 +57,23 @@ def build_models(depth, device):
     return models, sds
 
 
-def make_step(models, frames_t, frames_rgb, world, rank, with_comm=True, concurrent=True):
+def make_step(models, frames_t, frames_rgb, world, rank, with_comm=True, concurrent=True, stagger=0):
     from proben_amd.pipeline import FramePairPipeline
     B = frames_t.shape[0]
     out_sizes = [(512, 640)] * B
-    pipe = FramePairPipeline(models, "probEn", "v-avg", concurrent=concurrent)
+    pipe = FramePairPipeline(models, "probEn", "v-avg", concurrent=concurrent, staggered=stagger > 0, stagger_stage=stagger or 4)
 
     def step():
         (det_t, det_r), fused = pipe([frames_t, frames_rgb], out_sizes, (800, 1000))  # [B,512,640,3] uint8 batches
         if world > 1 and with_comm:
             from proben_amd import comm
-            comm.all_gather_fused_rows(fused)
+            if pipe.staggered:   # the fused rows live on the second detector's stream
+                with torch.cuda.stream(pipe.streams[1]):
+                    comm.all_gather_fused_rows(fused)
+            else:
+                comm.all_gather_fused_rows(fused)
         return det_t, det_r, fused
+    step.pipe = pipe
     return step
 
 
@@ -205,7 +211,7 @@ def main():
     B = args.batch
     frames_t = torch.from_numpy(synthetic_images(B, seed=10 + rank)).to(dev)
     frames_rgb = torch.from_numpy(synthetic_images(B, seed=1000 + rank)).to(dev)
-    step = make_step(models, frames_t, frames_rgb, world, rank, concurrent=not args.serial_detectors)
+    step = make_step(models, frames_t, frames_rgb, world, rank, concurrent=not args.serial_detectors, stagger=args.stagger)
 
     def fence():
         if world > 1:

@@ -12,17 +12,64 @@ from . import fusion as F
 
 
 class FramePairPipeline:
-    def __init__(self, models, score_fusion="probEn", box_fusion="v-avg", max_class=2, concurrent=True):
+    """concurrent: one HIP stream per detector.
+    staggered (throughput mode, two detectors): detector 1's stream starts a batch only when detector 0 has finished
+    its res`stagger_stage` stage, and nothing makes detector 0 wait for the fusion of the previous batch - in steady
+    state the two identical networks run half a forward pass apart, so one's MFMA-bound p2/p3 3x3 convolutions
+    share the chip with the other's HBM/latency-bound res4 1x1 chain instead of with their own kind.  The call
+    returns with work still in flight on the side streams: use the results after `wait()` (or a device
+    synchronisation); inputs must not be modified before that either."""
+
+    def __init__(self, models, score_fusion="probEn", box_fusion="v-avg", max_class=2, concurrent=True,
+                 staggered=False, stagger_stage=4):
         self.models = list(models)
         self.method = (score_fusion, box_fusion)
         self.max_class = max_class
         self.concurrent = concurrent and len(self.models) > 1
+        self.staggered = staggered and self.concurrent and len(self.models) == 2
+        self.stagger_stage = stagger_stage
         self.streams = [torch.cuda.Stream() for _ in self.models] if self.concurrent else None
+
+    def wait(self):
+        """Make the current stream wait for everything the pipeline has enqueued (staggered mode)."""
+        if self.streams:
+            main = torch.cuda.current_stream()
+            for st in self.streams:
+                main.wait_stream(st)
+
+    @torch.no_grad()
+    def _call_staggered(self, frames_per_detector, out_sizes, resize_to):
+        sa, sb = self.streams
+        ma, mb = self.models
+        main = torch.cuda.current_stream()
+        ev_in = torch.cuda.Event()
+        ev_in.record(main)              # inputs are ready; NOT a wait for earlier pipeline work (that lives on sa / sb)
+        ev_mid, ev_a = torch.cuda.Event(), torch.cuda.Event()
+        sa.wait_event(ev_in)
+        with torch.cuda.stream(sa):
+            ma.stage_hook = lambda stage: ev_mid.record(sa) if stage == self.stagger_stage else None
+            try:
+                det_a = ma.forward_batch(frames_per_detector[0], out_sizes=out_sizes, resize_to=resize_to)
+            finally:
+                ma.stage_hook = None
+            ev_a.record(sa)
+        sb.wait_event(ev_in)
+        sb.wait_event(ev_mid)
+        with torch.cuda.stream(sb):
+            det_b = mb.forward_batch(frames_per_detector[1], out_sizes=out_sizes, resize_to=resize_to)
+            sb.wait_event(ev_a)
+            for v in det_a.values():    # detector 0's results were allocated on sa and are read on sb
+                if isinstance(v, torch.Tensor):
+                    v.record_stream(sb)
+            fused = F.fuse_detections([det_a, det_b], self.method[0], self.method[1], max_class=self.max_class)
+        return [det_a, det_b], fused
 
     @torch.no_grad()
     def __call__(self, frames_per_detector, out_sizes, resize_to):
         """frames_per_detector[d]: the batch for detector d ([B,H,W,C] uint8/float tensor or list of tensors).
         Returns (list of per-detector result dicts, fused dict of fusion.fuse_detections)."""
+        if self.staggered:
+            return self._call_staggered(frames_per_detector, out_sizes, resize_to)
         if not self.concurrent:
             dets = [m.forward_batch(fr, out_sizes=out_sizes, resize_to=resize_to)
                     for m, fr in zip(self.models, frames_per_detector)]

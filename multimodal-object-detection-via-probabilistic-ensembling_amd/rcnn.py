@@ -104,6 +104,9 @@ class GeneralizedRCNN:
                 o = self._conv(o, p + ".conv2", kernel=3, relu=True)
                 x = self._conv(o, p + ".conv3", kernel=1, relu=True, residual=sc, residual_mode=1)
             outs.append(x)
+            hook = getattr(self, "stage_hook", None)
+            if hook is not None:
+                hook(si + 2)  # pipeline.py staggers the second detector's stream behind this point
         return outs  # res2..res5
 
     def _fpn(self, x, prefix="backbone", outs=None, ch_off=0, ch_total=256):

@@ -98,7 +98,8 @@ def test_predictor_and_device_stage_fusion():
 
 
 def test_frame_pair_pipeline_concurrent_equals_serial():
-    """Detectors on separate HIP streams (the bench configuration) give bit-identical results to the serial run."""
+    """Detectors on separate HIP streams (the bench configuration), and the staggered throughput mode with several
+    batches in flight, give bit-identical results to the serial run."""
     import proben_amd  # noqa: F401
     from proben_amd.pipeline import FramePairPipeline
     from proben_amd.rcnn import DetectorConfig, GeneralizedRCNN
@@ -107,9 +108,14 @@ def test_frame_pair_pipeline_concurrent_equals_serial():
     ft = torch.from_numpy(synthetic_images(4, 256, 320, seed=7)).cuda()
     fr = torch.from_numpy(synthetic_images(4, 256, 320, seed=8)).cuda()
     outs = []
-    for concurrent in (False, True, True):
-        pipe = FramePairPipeline(models, "probEn", "v-avg", concurrent=concurrent)
-        dets, fused = pipe([ft, fr], [(256, 320)] * 4, (800, 1000))
+    for concurrent, staggered in ((False, False), (True, False), (True, False), (True, True)):
+        pipe = FramePairPipeline(models, "probEn", "v-avg", concurrent=concurrent, staggered=staggered)
+        if staggered:   # throughput mode: several batches in flight, results valid after wait()
+            for _ in range(3):
+                dets, fused = pipe([ft, fr], [(256, 320)] * 4, (800, 1000))
+            pipe.wait()
+        else:
+            dets, fused = pipe([ft, fr], [(256, 320)] * 4, (800, 1000))
         torch.cuda.synchronize()
         outs.append((dets, fused))
     (d0, f0) = outs[0]
