@@ -43,6 +43,19 @@ __global__ __launch_bounds__(512, 2) void probe(const unsigned char* src, float*
             }
             acc_out += (float)s[0];
         }
+        if (mode_other & 4) {   // register-staged loop: 2 x (global_load_dwordx4 -> VGPR -> ds_write_b128) per iteration
+            const unsigned char* g = src + (size_t)blockIdx.x * 65536 + lane * 16;
+            unsigned char* l = smem + 65536 + w * 2048 + lane * 16;
+            half8 r0 = *reinterpret_cast<const half8*>(g), r1 = *reinterpret_cast<const half8*>(g + 1024);
+            for (int it = 1; it <= iters; ++it) {
+                const half8 n0 = *reinterpret_cast<const half8*>(g + ((it * 2) & 63) * 1024);
+                const half8 n1 = *reinterpret_cast<const half8*>(g + ((it * 2 + 1) & 63) * 1024);
+                *reinterpret_cast<half8*>(l) = r0;
+                *reinterpret_cast<half8*>(l + 1024) = r1;
+                r0 = n0; r1 = n1;
+            }
+            acc_out += (float)r0[0] + (float)r1[0];
+        }
         if (mode_other & 2) {   // LDS-DMA loop: 2 x 1 KiB per iteration from an L2-resident 64 KiB window per CU
             const unsigned char* g = src + (size_t)blockIdx.x * 65536 + lane * 16;
             for (int it = 0; it < iters; ++it) {
@@ -64,9 +77,10 @@ int main() {
     hipFuncSetAttribute((const void*)probe, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     printf("%-34s %10s %12s %14s %14s\n", "config", "ms", "MFMA TF/s", "LDS rd B/clk/CU", "DMA GB/s/CU");
-    const char* names[] = {"other waves idle", "other waves: ds_read_b128", "other waves: global_load_lds", "other waves: both"};
+    const char* names[] = {"other waves idle", "other waves: ds_read_b128", "other waves: global_load_lds", "other waves: both",
+                           "other waves: load + ds_write", "other waves: ld+ds_write+ds_read"};
     for (int mm = 1; mm >= 0; --mm)
-        for (int mo = 0; mo < 4; ++mo) {
+        for (int mo = 0; mo < 6; ++mo) {
             if (!mm && !mo) continue;
             for (int rep = 0; rep < 2; ++rep) {
                 hipEventRecord(e0);
@@ -76,7 +90,7 @@ int main() {
             float ms; hipEventElapsedTime(&ms, e0, e1);
             const double tf = mm ? 2.0 * 32 * 32 * 16 * 8.0 * iters * 4 * blocks / (ms * 1e-3) / 1e12 : 0;
             const double rd = (mo & 1) ? 12.0 * 1024 * iters * 4 / (ms * 1e-3) / 2.1e9 : 0;   // bytes per clock at 2.1 GHz
-            const double dma = (mo & 2) ? 2.0 * 1024 * iters * 4 / (ms * 1e-3) / 1e9 : 0;
+            const double dma = (mo & 6) ? 2.0 * 1024 * iters * 4 / (ms * 1e-3) / 1e9 : 0;
             char label[64]; snprintf(label, sizeof label, "%s%s", mm ? "MFMA + " : "no MFMA, ", names[mo]);
             printf("%-34s %10.3f %12.0f %14.1f %14.1f\n", label, ms, tf, rd, dma);
         }
