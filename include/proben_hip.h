@@ -124,7 +124,9 @@ int pe_set_conv_ablation(int32_t mode);
  *   4: two-stage pipeline in the generic 1x1 kernel                              8: 256x256 two-stage kernel for long-K GEMMs
  *  16: 256x256 kernel for every eligible launch                                 32: double-buffered weight tile in the 3x3 kernel
  *  64: experimental 256x256 four-stage ring kernel (counted vmcnt, raw barriers) for every eligible launch
- * 128: experimental 256x256 phase-split kernel (quadrant phases, staggered wave rows, s_setprio) for every eligible launch */
+ * 128: experimental 256x256 phase-split kernel (quadrant phases, staggered wave rows, s_setprio) for every eligible launch
+ * 256: experimental 512-row / 16-wave tiles in the kw-reuse 3x3 kernel
+ * 1024: experimental 256x256 phase-split kernel on the kw-reuse slab (3x3 only) */
 int pe_set_conv_tile256(int32_t mode);
 
 /* ---------------------------------------------------------------------------------------------

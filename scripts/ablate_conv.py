@@ -33,7 +33,7 @@ def main():
         out = torch.empty(N, H, W, Cout, device="cuda", dtype=torch.float16)
         fl = 2.0 * N * H * W * Cout * k * k * Cin
         row = []
-        for impl, abl, tile in [(1, 0, 1), (3, 0, 1), (2, 0, 0), (2, 0, 1), (2, 0, 3), (2, 0, 33), (2, 0, 25), (2, 0, 128), (2, 0, 297)]:
+        for impl, abl, tile in [(1, 0, 1), (3, 0, 1), (2, 0, 0), (2, 0, 1), (2, 0, 3), (2, 0, 33), (2, 0, 25), (2, 0, 128), (2, 0, 41 | 1024)]:
             lib.pe_set_conv_impl(impl)
             lib.pe_set_conv_ablation(abl)
             lib.pe_set_conv_tile256(tile)

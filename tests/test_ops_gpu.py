@@ -128,6 +128,28 @@ def test_conv3x3_weight_double_buffered_kernel(L, case):
     torch.testing.assert_close(out.permute(0, 3, 1, 2).float(), ref, rtol=4e-3, atol=4e-3)
 
 
+@pytest.mark.parametrize("case", [(8, 100, 128, 128, 256), (9, 99, 131, 64, 256), (16, 51, 67, 256, 512), (5, 200, 256, 192, 256)])
+def test_conv3x3_phase_split_slab_kernel(L, case):
+    """The experimental 256x256 phase-split kernel with the kw-reuse slab (tile policy bit 10): ragged M, image-row
+    wrap inside a tile, minimal (3 groups) and odd (9 groups) group counts, two N tiles; run twice (race screen)."""
+    import proben_amd
+    N, H, W, Cin, Cout = case
+    lib = proben_amd._lib.lib()
+    g = torch.Generator(device="cpu").manual_seed(17)
+    x = torch.randn(N, Cin, H, W, generator=g).cuda().half()
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5).cuda().half()
+    b = torch.randn(Cout, generator=g).cuda()
+    ref = torch.nn.functional.conv2d(x.float(), w.float(), b, stride=1, padding=1).relu()
+    lib.pe_set_conv_tile256(41 | 1024)
+    try:
+        outs = [L.conv2d_nhwc(nhwc(x), w.permute(0, 2, 3, 1).contiguous(), b, kernel=3, relu=True) for _ in range(2)]
+        torch.cuda.synchronize()
+    finally:
+        lib.pe_set_conv_tile256(41)
+    assert torch.equal(outs[0], outs[1])
+    torch.testing.assert_close(outs[0].permute(0, 3, 1, 2).float(), ref, rtol=4e-3, atol=4e-3)
+
+
 def test_conv_transpose_detecting(L):
     """A = identity-like pixels, ASYMMETRIC weights: catches a row/col swap in the MFMA C layout."""
     Cin = Cout = 128
