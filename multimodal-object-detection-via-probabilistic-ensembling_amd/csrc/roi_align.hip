@@ -77,6 +77,9 @@ struct Vec<float> {
 // 256 threads then only do load + 8 fused multiply-adds per pixel (the tap form spends ~100 VALU instructions per
 // sample on coordinates and fp16 -> fp32 converts, which made it VALU-issue bound).  Summation order differs
 // from the reference kernel, which is why fp32 features keep the tap form (bit-exact).
+#ifndef ROI_MLP
+#define ROI_MLP 4
+#endif
 constexpr int SEP_MAXB = 8;    // pooled bins per axis
 constexpr int SEP_MAXN = 20;   // pixels per bin per axis (grid <= ~18); larger ROIs fall back to the tap form
 
@@ -178,18 +181,19 @@ __global__ __launch_bounds__(256) void roi_align_kernel(RoiArgs a) {
             const float* wyr = tabs.w[0][ph];
             const float* wxr = tabs.w[1][pw];
             int rr = 0, c = 0;
-            for (int i = 0; i < npx; i += 4) {  // 4 independent 16-byte loads in flight per lane
-                half8 h[4];
-                float w[4];
+            constexpr int MLP = ROI_MLP;   // independent 16-byte loads in flight per lane
+            for (int i = 0; i < npx; i += MLP) {
+                half8 h[MLP];
+                float w[MLP];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < MLP; ++u) {
                     const bool ok = i + u < npx;
                     w[u] = ok ? wyr[rr] * wxr[c] : 0.f;
                     h[u] = *reinterpret_cast<const half8*>(base + ((size_t)rr * W + c) * a.C);
                     if (i + u + 1 < npx && ++c == nx) { c = 0; ++rr; }   // stays on the last pixel past the end
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
+                for (int u = 0; u < MLP; ++u)
 #pragma unroll
                     for (int e = 0; e < V; ++e) acc[e] = __builtin_fmaf((float)h[u][e], w[u], acc[e]);
             }
