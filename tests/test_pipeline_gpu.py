@@ -208,3 +208,36 @@ def test_device_rows_match_host_evaluator_rows():
         assert int(r[0]) == w["image_id"] and int(r[6]) == w["category_id"]
         np.testing.assert_allclose(r[1:5], w["bbox"], rtol=1e-5, atol=1e-4)   # the host path goes through float32 boxes
         assert r[5] == pytest.approx(w["score"], rel=1e-6)
+
+
+def test_full_size_pipeline_deterministic_and_batch_invariant():
+    """BASELINE configs[2] at its real size (two R101-FPN detectors, 640x512 frames -> 800x1000, ProbEn probEn / v-avg):
+    two runs of a batch of 8 pairs are bit-identical, and pair 5's fused rows equal those of a batch holding only
+    that pair (size-independent properties; the oracle comparison at this size is test_r101_full_size_matches_oracle)."""
+    import proben_amd  # noqa: F401
+    from proben_amd.pipeline import FramePairPipeline
+    from proben_amd.rcnn import DetectorConfig, GeneralizedRCNN
+    from proben_amd.synthetic import synthetic_images, synthetic_state_dict
+    models = [GeneralizedRCNN(DetectorConfig(), synthetic_state_dict(101, 3, 3, seed=s)) for s in (1, 2)]
+    ft = torch.from_numpy(synthetic_images(8, seed=21)).cuda()
+    fr = torch.from_numpy(synthetic_images(8, seed=22)).cuda()
+    pipe = FramePairPipeline(models, "probEn", "v-avg")
+    runs = []
+    for _ in range(2):
+        dets, fused = pipe([ft, fr], [(512, 640)] * 8, (800, 1000))
+        torch.cuda.synchronize()
+        runs.append((dets, fused))
+    (d0, f0), (d1, f1) = runs
+    for a, b in zip(d0, d1):
+        for k in ("boxes", "scores", "classes", "counts", "vars", "prob_score"):
+            assert torch.equal(a[k], b[k]), k
+    for k in ("boxes", "scores", "classes", "counts", "offsets"):
+        assert torch.equal(f0[k], f1[k]), k
+    assert int(f0["counts"].sum()) > 0
+    _, one = pipe([ft[5:6], fr[5:6]], [(512, 640)], (800, 1000))
+    torch.cuda.synchronize()
+    o, c = int(f0["offsets"][5]), int(f0["counts"][5])
+    assert c == int(one["counts"][0])
+    o1 = int(one["offsets"][0])
+    for k in ("boxes", "scores", "classes"):
+        assert torch.equal(f0[k][o:o + c], one[k][o1:o1 + c]), k
