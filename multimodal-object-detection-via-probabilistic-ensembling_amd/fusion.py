@@ -150,7 +150,10 @@ def fuse_detections(dets, score_fusion="probEn", box_fusion="v-avg", max_class=2
         from .layers import nms_batched_raw
         b32 = ob.float().view(B, S, 4)
         keep, kcnt = nms_batched_raw(b32, os_.float().view(B, S), oc.view(B, S), ocnt, None, iou_thresh, 0, S)
-        # TODO(next round): passthrough images on this route still go through NMS
+        # images where only ONE detector fired are passed through untouched by the reference (demo_probEn.py:239-254)
+        single = osingle.bool()
+        keep = torch.where(single[:, None], torch.arange(S, dtype=torch.int32, device=dev).expand(B, S), keep)
+        kcnt = torch.where(single, ocnt, kcnt)
         return {"keep": keep, "counts": kcnt, "boxes": ob, "scores": os_.float(), "classes": oc.float(),
                 "offsets": ooff, "stride": S, "nms_route": True}
     out = fuse_batch(ob, os_, op, ov, oc, ooff, score_fusion, box_fusion, max_rows=S, iou_thresh=iou_thresh,

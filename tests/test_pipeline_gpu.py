@@ -95,6 +95,22 @@ def test_predictor_and_device_stage_fusion():
         np.testing.assert_array_equal(fused["classes"][sl].cpu().numpy(), c.numpy())
         np.testing.assert_allclose(fused["scores"][sl].cpu().numpy(), s.numpy(), rtol=1e-6, equal_nan=True)
         np.testing.assert_allclose(fused["boxes"][sl].cpu().numpy(), np.asarray(b), rtol=1e-9, atol=1e-9, equal_nan=True)
+    # (max, argmax) = nms_1 route (demo_probEn.py:44-71,189-196); image 1 is made a one-detector image: passthrough
+    dets[1]["counts"][1] = 0
+    j1[1] = LF.predictions_to_j1([f"im{i}.jpeg" for i in range(3)], list(range(3)),
+                                 [o["instances"] for o in preds[1].model.to_instances(dets[1])])
+    fused = F.fuse_detections(dets, "max", "argmax")
+    host = LF.late_fusion(j1, ["max", "argmax"])
+    assert fused["nms_route"]
+    kc, off = fused["counts"].cpu().numpy(), fused["offsets"].cpu().numpy()
+    for i in range(3):
+        b, sc, c = host[i]
+        rows = off[i] + fused["keep"][i, : kc[i]].cpu().numpy()
+        assert kc[i] == len(sc), i
+        np.testing.assert_allclose(fused["scores"][rows].cpu().numpy(), sc.numpy(), rtol=1e-6)
+        np.testing.assert_array_equal(fused["classes"][rows].cpu().numpy(), np.asarray(c, dtype=np.float32))
+        np.testing.assert_allclose(fused["boxes"][rows].cpu().numpy(), np.asarray(b, dtype=np.float64), rtol=1e-6, atol=1e-4)
+    assert kc[1] == int(dets[0]["counts"][1])   # untouched list of the only detector that fired
 
 
 def test_frame_pair_pipeline_concurrent_equals_serial():
