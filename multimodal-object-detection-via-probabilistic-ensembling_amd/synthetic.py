@@ -47,7 +47,7 @@ def synth_detections(num_images, seed, kdet=2, nmax=100, K=3, dup_frac=0.3, jitt
 # Random-init detector weights (no checkpoints exist offline).  Key names follow the reference's
 # state dict (SURVEY A.3 / detectron2 module tree) so a real `.pth` drops in unchanged.
 # ------------------------------------------------------------------------------------------------
-STAGE_BLOCKS = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3), 152: (3, 8, 36, 3)}  # backbone/resnet.py:440-441
+STAGE_BLOCKS = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3), 152: (3, 8, 36, 3)}  # backbone/resnet.py:515-519
 
 
 def synthetic_state_dict(depth=101, num_classes=3, in_channels=3, seed=1, cls_std=0.1, obj_std=0.1, two_backbones=False):

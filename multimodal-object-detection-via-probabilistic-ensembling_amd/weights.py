@@ -13,7 +13,7 @@ tensors the HIP kernels consume:
 import torch
 
 BN_EPS = 1e-5
-STAGE_BLOCKS = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3), 152: (3, 8, 36, 3)}  # backbone/resnet.py:440-441
+STAGE_BLOCKS = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3), 152: (3, 8, 36, 3)}  # backbone/resnet.py:515-519
 
 
 def load_state_dict_file(path):
