@@ -134,3 +134,9 @@ def test_batch_invariance_full_batch():
         assert c == int(big["counts"][i])
         for k in ("boxes", "scores", "classes", "class_logits", "prob_score", "vars"):
             assert torch.equal(one[k][0, :c], big[k][i, :c]), k
+
+
+def test_r152_matches_oracle():
+    """The reference's build_resnet_backbone also offers depth 152 (backbone/resnet.py:515-519): (3, 8, 36, 3) blocks."""
+    want, inter, det, _ = run_pair(152, hw=(256, 320), n_images=2)
+    check_pair(want, inter, det)
