@@ -134,8 +134,9 @@ int pe_set_conv_tile256(int32_t mode);
  * pe_preprocess_pack: one image -> normalised, zero-padded NHWC4 fp16 (optionally bilinear-resized first).
  *   Replaces GeneralizedRCNN.preprocess_image (modeling/meta_arch/rcnn.py:269-286), ImageList.from_tensors
  *   (structures/image_list.py:51-102) and, when dst size != src size, ResizeTransform.apply_image
- *   (data/transforms/transform.py:81-98; half-pixel bilinear, uint8 sources rounded back to integers -
- *   parity with PIL / cv2 resampling is unpinned).
+ *   (data/transforms/transform.py:81-98; half-pixel bilinear, uint8 sources rounded back to integers: this is the
+ *   stand-in for the cv2.resize branch of the 4- / 6-channel inputs, parity unpinned; 3-channel uint8 images use
+ *   pe_preprocess_pack_pil_u8 below, which is Pillow-exact).
  *   src_kind 0: HWC uint8, 1: HWC float32, 2: CHW float32.  Source channels [ch0, ch0+nch) -> output
  *   channels 0..nch-1 (flip_rgb reverses the first three); mean/std are HOST arrays of length nch.
  * pe_maxpool3x3s2_nhwc: F.max_pool2d(x, 3, 2, 1) of BasicStem.forward (modeling/backbone/resnet.py:383).
@@ -150,6 +151,15 @@ int pe_preprocess_pack_batch(const void* src, int32_t num_images, int32_t src_ki
                              int32_t src_c, int32_t ch0, int32_t nch, int32_t flip_rgb, int32_t dst_h, int32_t dst_w,
                              int32_t pad_h, int32_t pad_w, const float* mean_host, const float* std_host, void* dst,
                              void* stream);
+/* The same with Pillow's EXACT bilinear resampler for uint8 sources [N,src_h,src_w,src_c] - the reference resizes
+ * 3-channel images with Image.fromarray(img.astype(uint8)).resize((w, h), BILINEAR) (data/transforms/transform.py:92-97):
+ * horizontal pass rounded to uint8, then vertical pass, 22-bit fixed-point weights.  xtab [dst_w, 2 + xk] /
+ * ytab [dst_h, 2 + yk] DEVICE int32 tables (first tap, tap count, weights) of libImaging/Resample.c
+ * precompute_coeffs + normalize_coeffs_8bpc (host helper: proben_amd.data.pil_bilinear_tables). */
+int pe_preprocess_pack_pil_u8(const void* src, int32_t num_images, int32_t src_h, int32_t src_w, int32_t src_c,
+                              int32_t ch0, int32_t nch, int32_t flip_rgb, int32_t dst_h, int32_t dst_w, int32_t pad_h,
+                              int32_t pad_w, const float* mean_host, const float* std_host, const int32_t* xtab,
+                              int32_t xk, const int32_t* ytab, int32_t yk, void* dst, void* stream);
 int pe_maxpool3x3s2_nhwc(const void* in, void* out, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
 int pe_subsample2_nhwc(const void* in, void* out, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
 /* Fused BasicStem.forward (modeling/backbone/resnet.py:375-384): conv 7x7 / 2 / pad 3 with the frozen BN folded

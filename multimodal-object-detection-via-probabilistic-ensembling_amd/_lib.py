@@ -22,6 +22,7 @@ SIGNATURES = {
     "pe_set_conv_tile256": [c_int],
     "pe_preprocess_pack": [c_void_p] + [c_int] * 11 + [c_void_p] * 4,
     "pe_preprocess_pack_batch": [c_void_p] + [c_int] * 12 + [c_void_p] * 4,
+    "pe_preprocess_pack_pil_u8": [c_void_p] + [c_int] * 11 + [c_void_p] * 2 + [c_void_p, c_int, c_void_p, c_int] + [c_void_p] * 2,
     "pe_maxpool3x3s2_nhwc": [c_void_p] * 2 + [c_int] * 4 + [c_void_p],
     "pe_subsample2_nhwc": [c_void_p] * 2 + [c_int] * 4 + [c_void_p],
     "pe_stem_conv7x7_maxpool_f16": [c_void_p] * 4 + [c_int] * 3 + [c_void_p],

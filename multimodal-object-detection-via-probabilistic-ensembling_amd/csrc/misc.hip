@@ -69,6 +69,56 @@ __global__ void preprocess_pack_kernel(PackArgs a) {
     *reinterpret_cast<half4*>(a.dst + ((size_t)y * a.pad_w + x) * 4) = o;
 }
 
+// Pillow-exact bilinear resize of uint8 images (two passes, each rounded to uint8: libImaging/Resample.c
+// ImagingResampleHorizontal_8bpc / Vertical_8bpc) fused with normalise + pad + NHWC4 pack.  xtab / ytab rows:
+// (first tap, tap count, 22-bit weights...) from proben_amd.data.pil_bilinear_tables.
+struct PilArgs {
+    const unsigned char* src;   // [N, src_h, src_w, src_c] uint8
+    int src_h, src_w, src_c, ch0, nch, flip_rgb;
+    int dst_h, dst_w, pad_h, pad_w;
+    const int32_t* xtab; int xk;   // [dst_w, 2 + xk]
+    const int32_t* ytab; int yk;   // [dst_h, 2 + yk]
+    float mean[4], inv_std[4];
+    _Float16* dst;
+};
+
+__device__ __forceinline__ int clip8(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
+
+template <int NCH, bool FLIP>
+__global__ void preprocess_pil_kernel(PilArgs a) {
+    const unsigned char* src = a.src + (size_t)blockIdx.z * a.src_h * a.src_w * a.src_c;
+    _Float16* dst = a.dst + (size_t)blockIdx.z * a.pad_h * a.pad_w * 4;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= a.pad_w) return;
+    half4 o = {0, 0, 0, 0};
+    if (y < a.dst_h && x < a.dst_w) {
+        const int32_t* xt = a.xtab + (size_t)x * (2 + a.xk);
+        const int32_t* yt = a.ytab + (size_t)y * (2 + a.yk);   // wave-uniform: scalar loads
+        const int xmin = xt[0], nx = xt[1], ymin = yt[0], ny = yt[1];
+        int accv[NCH];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) accv[c] = 1 << 21;
+        for (int j = 0; j < ny; ++j) {
+            const unsigned char* row = src + ((size_t)(ymin + j) * a.src_w + xmin) * a.src_c + a.ch0;
+            int acch[NCH];
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) acch[c] = 1 << 21;
+            for (int i = 0; i < nx; ++i) {
+                const int k = xt[2 + i];
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) acch[c] += (int)row[i * a.src_c + ((FLIP && c < 3) ? 2 - c : c)] * k;
+            }
+            const int k = yt[2 + j];
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) accv[c] += clip8(acch[c] >> 22) * k;   // the horizontal pass result is a uint8 image
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) o[c] = (_Float16)(((float)clip8(accv[c] >> 22) - a.mean[c]) * a.inv_std[c]);
+    }
+    *reinterpret_cast<half4*>(dst + ((size_t)y * a.pad_w + x) * 4) = o;
+}
+
 __global__ void maxpool3x3s2_kernel(const _Float16* in, _Float16* out, int N, int H, int W, int C, int Ho, int Wo) {
     const int cv = C / 8;
     const size_t total = (size_t)N * Ho * Wo * cv;
@@ -152,6 +202,42 @@ extern "C" int pe_preprocess_pack_batch(const void* src, int32_t num_images, int
                                         const float* mean_host, const float* std_host, void* dst, void* stream) {
     return preprocess_launch(src, num_images, src_kind, src_h, src_w, src_c, ch0, nch, flip_rgb, dst_h, dst_w, pad_h,
                              pad_w, mean_host, std_host, dst, stream);
+}
+
+extern "C" int pe_preprocess_pack_pil_u8(const void* src, int32_t num_images, int32_t src_h, int32_t src_w, int32_t src_c,
+                                         int32_t ch0, int32_t nch, int32_t flip_rgb, int32_t dst_h, int32_t dst_w,
+                                         int32_t pad_h, int32_t pad_w, const float* mean_host, const float* std_host,
+                                         const int32_t* xtab, int32_t xk, const int32_t* ytab, int32_t yk, void* dst,
+                                         void* stream) {
+    PE_CHECK_ARG(src && dst && mean_host && std_host && xtab && ytab, "pe_preprocess_pack_pil_u8: null pointer");
+    PE_CHECK_ARG(nch >= 1 && nch <= 4 && ch0 >= 0 && ch0 + nch <= src_c, "pe_preprocess_pack_pil_u8: channel window [%d,%d) of %d",
+                 ch0, ch0 + nch, src_c);
+    PE_CHECK_ARG(dst_h <= pad_h && dst_w <= pad_w && dst_h > 0 && dst_w > 0 && xk >= 1 && yk >= 1, "pe_preprocess_pack_pil_u8: bad sizes");
+    PE_CHECK_ARG(num_images >= 1 && num_images <= 65535, "pe_preprocess_pack_pil_u8: num_images %d", num_images);
+    PilArgs a{};
+    a.src = (const unsigned char*)src; a.src_h = src_h; a.src_w = src_w; a.src_c = src_c; a.ch0 = ch0; a.nch = nch;
+    a.flip_rgb = flip_rgb; a.dst_h = dst_h; a.dst_w = dst_w; a.pad_h = pad_h; a.pad_w = pad_w;
+    a.xtab = xtab; a.xk = xk; a.ytab = ytab; a.yk = yk; a.dst = (_Float16*)dst;
+    for (int c = 0; c < 4; ++c) {
+        a.mean[c] = c < nch ? mean_host[c] : 0.f;
+        a.inv_std[c] = c < nch ? 1.f / std_host[c] : 0.f;
+    }
+    const dim3 grid(pe::ceil_div(pad_w, 256), pad_h, num_images), block(256);
+    hipStream_t st = (hipStream_t)stream;
+#define PE_PIL_LAUNCH(N, F) hipLaunchKernelGGL((preprocess_pil_kernel<N, F>), grid, block, 0, st, a)
+    switch (nch * 2 + (flip_rgb ? 1 : 0)) {
+        case 2: PE_PIL_LAUNCH(1, false); break;
+        case 3: PE_PIL_LAUNCH(1, true); break;
+        case 4: PE_PIL_LAUNCH(2, false); break;
+        case 5: PE_PIL_LAUNCH(2, true); break;
+        case 6: PE_PIL_LAUNCH(3, false); break;
+        case 7: PE_PIL_LAUNCH(3, true); break;
+        case 8: PE_PIL_LAUNCH(4, false); break;
+        default: PE_PIL_LAUNCH(4, true); break;
+    }
+#undef PE_PIL_LAUNCH
+    PE_CHECK_LAUNCH("pe_preprocess_pack_pil_u8");
+    return PE_OK;
 }
 
 extern "C" int pe_maxpool3x3s2_nhwc(const void* in, void* out, int32_t N, int32_t H, int32_t W, int32_t C, void* stream) {

@@ -97,6 +97,38 @@ def resize_shortest_edge_shape(h, w, short_edge_length=800, max_size=1333):
     return int(newh + 0.5), int(neww + 0.5)
 
 
+PIL_PRECISION_BITS = 32 - 8 - 2
+
+
+def pil_bilinear_tables(in_size, out_size):
+    """Fixed-point tap tables of Pillow's bilinear resampler for one axis (libImaging/Resample.c precompute_coeffs +
+    normalize_coeffs_8bpc; the reference resizes 3-channel images with Image.resize(..., BILINEAR),
+    data/transforms/transform.py:92-97).  Returns int32 [out_size, 2 + ksize]: first tap, tap count, 22-bit weights.
+    float64 arithmetic in Pillow's order, so the integers are Pillow's integers (tests/test_oracle_resize.py)."""
+    scale = filterscale = float(in_size) / float(out_size)
+    filterscale = max(filterscale, 1.0)
+    support = 1.0 * filterscale
+    ksize = int(np.ceil(support)) * 2 + 1
+    ss = 1.0 / filterscale
+    center = (np.arange(out_size, dtype=np.float64) + 0.5) * scale
+    xmin = np.maximum(np.trunc(center - support + 0.5), 0.0).astype(np.int64)
+    xmax = np.minimum(np.trunc(center + support + 0.5), float(in_size)).astype(np.int64)
+    n = xmax - xmin
+    w = np.zeros((out_size, ksize), dtype=np.float64)
+    ww = np.zeros(out_size, dtype=np.float64)
+    for x in range(ksize):
+        v = np.abs((x + xmin - center + 0.5) * ss)
+        wx = np.where((v < 1.0) & (x < n), 1.0 - v, 0.0)
+        w[:, x] = wx
+        ww = ww + wx              # same left-to-right sum as the C loop
+    nz = ww != 0.0
+    w[nz] = w[nz] / ww[nz, None]
+    tab = np.empty((out_size, 2 + ksize), dtype=np.int32)
+    tab[:, 0], tab[:, 1] = xmin, n
+    tab[:, 2:] = np.trunc(0.5 + w * float(1 << PIL_PRECISION_BITS)).astype(np.int32)
+    return tab
+
+
 class InferenceSampler:
     """Contiguous per-rank index blocks of ceil(N / W)."""
 

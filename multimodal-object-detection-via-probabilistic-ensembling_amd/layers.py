@@ -228,6 +228,34 @@ def preprocess_pack(src, dst, *, src_kind, ch0, nch, flip_rgb, dst_hw, mean, std
     _lib.check(st, "pe_preprocess_pack")
 
 
+_PIL_TABLES = {}
+
+
+def _pil_tables(in_size, out_size, device):
+    key = (in_size, out_size, str(device))
+    if key not in _PIL_TABLES:
+        from .data import pil_bilinear_tables
+        _PIL_TABLES[key] = torch.from_numpy(pil_bilinear_tables(in_size, out_size)).to(device)
+    return _PIL_TABLES[key]
+
+
+def preprocess_pack_pil_u8(src, dst, *, ch0, nch, flip_rgb, dst_hw, mean, std):
+    """src: [N,H,W,C] uint8 batch (or one [H,W,C] image with dst [pad_h,pad_w,4]); Pillow-exact bilinear resize to
+    dst_hw, then normalise / pad / NHWC4 fp16 pack (the reference's 3-channel path, transform.py:92-97)."""
+    _lib.require_cuda(src, dst)
+    if src.dim() == 3:
+        src, dst = src.unsqueeze(0), dst.unsqueeze(0)
+    assert src.dtype == torch.uint8 and src.is_contiguous()
+    n, h, w, c = src.shape
+    xt, yt = _pil_tables(w, dst_hw[1], src.device), _pil_tables(h, dst_hw[0], src.device)
+    m = (ctypes.c_float * 4)(*(list(mean) + [0.0] * (4 - len(mean))))
+    s = (ctypes.c_float * 4)(*(list(std) + [1.0] * (4 - len(std))))
+    st = _lib.lib().pe_preprocess_pack_pil_u8(_lib.ptr(src), n, h, w, c, ch0, nch, int(flip_rgb), dst_hw[0], dst_hw[1],
+                                              dst.shape[1], dst.shape[2], m, s, _lib.ptr(xt), xt.shape[1] - 2,
+                                              _lib.ptr(yt), yt.shape[1] - 2, _lib.ptr(dst), _lib.stream())
+    _lib.check(st, "pe_preprocess_pack_pil_u8")
+
+
 def preprocess_pack_batch(src, dst, *, src_kind, ch0, nch, flip_rgb, dst_hw, mean, std):
     """src: [N,H,W,C] (u8 / f32) or [N,C,H,W] f32 batch of equally sized images; dst: [N,pad_h,pad_w,4] fp16."""
     _lib.require_cuda(src, dst)

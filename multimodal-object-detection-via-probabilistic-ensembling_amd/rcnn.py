@@ -157,6 +157,11 @@ class GeneralizedRCNN:
         for ch0, nch in groups:
             x = torch.empty((N, Hp, Wp, 4), dtype=torch.float16, device=self.device)
             for i, im in enumerate(images):
+                if kinds[i] == 0 and C == 3 and tuple(sizes[i]) != tuple(im.shape[:2]):
+                    # 3-channel uint8 + resize: the reference goes through Pillow (transform.py:92-97) - exact restatement
+                    L.preprocess_pack_pil_u8(im.contiguous(), x[i], ch0=ch0, nch=nch, flip_rgb=False, dst_hw=sizes[i],
+                                             mean=mean[ch0:ch0 + nch], std=std[ch0:ch0 + nch])
+                    continue
                 L.preprocess_pack(im.contiguous(), x[i], src_kind=kinds[i], ch0=ch0, nch=nch, flip_rgb=False,
                                   dst_hw=sizes[i], mean=mean[ch0:ch0 + nch], std=std[ch0:ch0 + nch])
             batches.append(x)
@@ -178,6 +183,11 @@ class GeneralizedRCNN:
         batches = []
         for ch0, nch in ([(0, min(C, 4))] if C <= 4 else [(0, 3), (3, 3)]):
             x = torch.empty((N, Hp, Wp, 4), dtype=torch.float16, device=self.device)
+            if kind == 0 and C == 3 and tuple(size) != (h, w):   # Pillow-exact resize (see _preprocess)
+                L.preprocess_pack_pil_u8(images.contiguous(), x, ch0=ch0, nch=nch, flip_rgb=False, dst_hw=size,
+                                         mean=mean[ch0:ch0 + nch], std=std[ch0:ch0 + nch])
+                batches.append(x)
+                continue
             L.preprocess_pack_batch(images.contiguous(), x, src_kind=kind, ch0=ch0, nch=nch, flip_rgb=False, dst_hw=size,
                                     mean=mean[ch0:ch0 + nch], std=std[ch0:ch0 + nch])
             batches.append(x)

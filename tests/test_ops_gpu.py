@@ -241,6 +241,26 @@ def rand_boxes(g, n, span=600.0, wh=120.0):
     return torch.cat([xy, xy + torch.rand(n, 2, generator=g) * wh + 1], 1)
 
 
+@pytest.mark.parametrize("case", [(2, 48, 60, 75, 94), (1, 64, 64, 31, 47), (1, 512, 640, 800, 1000), (3, 90, 30, 135, 30)])
+def test_preprocess_pil_exact_vs_oracle(L, case):
+    """3-channel uint8 frames are resized exactly like Pillow (the reference's path, transform.py:92-97): every packed
+    fp16 value equals (pillow_resize(img) - mean) / std computed from the oracle's restatement; padding is zero."""
+    from oracle import resize as R
+    n, h, w, nh, nw = case
+    img = np.random.default_rng(h + w).integers(0, 256, size=(n, h, w, 3), dtype=np.uint8)
+    img[0, : h // 3] = 255
+    ph, pw = (nh + 31) // 32 * 32, (nw + 31) // 32 * 32
+    mean, std = [103.53, 116.28, 123.675], [1.0, 57.375, 2.0]
+    dst = torch.full((n, ph, pw, 4), 7.0, dtype=torch.float16, device="cuda")
+    L.preprocess_pack_pil_u8(torch.from_numpy(img).cuda(), dst, ch0=0, nch=3, flip_rgb=False, dst_hw=(nh, nw), mean=mean, std=std)
+    got = dst.cpu().numpy()
+    inv = np.float32(1.0) / np.asarray(std, dtype=np.float32)
+    for i in range(n):
+        want = ((R.pil_bilinear_resize_u8(img[i], nh, nw).astype(np.float32) - np.asarray(mean, dtype=np.float32)) * inv).astype(np.float16)
+        assert np.array_equal(got[i, :nh, :nw, :3], want), i
+    assert (got[:, nh:] == 0).all() and (got[:, :, nw:] == 0).all() and (got[..., 3] == 0).all()
+
+
 @pytest.mark.parametrize("n,ncls,thr", [(1, 1, 0.5), (300, 3, 0.5), (4624, 5, 0.7), (6000, 4, 0.5)])
 def test_batched_nms_matches_oracle(L, n, ncls, thr):
     from oracle import nms as O
