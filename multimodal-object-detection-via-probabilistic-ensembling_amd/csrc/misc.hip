@@ -43,23 +43,30 @@ __global__ void preprocess_pack_kernel(PackArgs a) {
         const bool resize = a.dst_h != a.src_h || a.dst_w != a.src_w;
         float sy = 0.f, sx = 0.f;
         int y0 = y, x0 = x, y1 = y, x1 = x;
-        if (resize) {  // bilinear, half-pixel centres, edge clamp
-            sy = ((float)y + 0.5f) * ((float)a.src_h / (float)a.dst_h) - 0.5f;
-            sx = ((float)x + 0.5f) * ((float)a.src_w / (float)a.dst_w) - 0.5f;
-            sy = fminf(fmaxf(sy, 0.f), (float)(a.src_h - 1));
-            sx = fminf(fmaxf(sx, 0.f), (float)(a.src_w - 1));
-            y0 = (int)sy; x0 = (int)sx;
-            y1 = min(y0 + 1, a.src_h - 1); x1 = min(x0 + 1, a.src_w - 1);
+        if (resize) {
+            // cv2.resize(..., INTER_LINEAR) on floating-point images (the reference's 4- / 6-channel branch,
+            // transform.py:82-91), restated from OpenCV's resizeGeneric_ (third-party, absent here: parity unpinned):
+            // source coordinate in double, cast to float; border taps collapse onto the edge pixel; float weights;
+            // horizontal then vertical pass accumulated in double
+            const double fy = ((double)y + 0.5) * ((double)a.src_h / (double)a.dst_h) - 0.5;
+            const double fx = ((double)x + 0.5) * ((double)a.src_w / (double)a.dst_w) - 0.5;
+            sy = (float)fy; sx = (float)fx;
+            y0 = (int)floorf(sy); x0 = (int)floorf(sx);
             sy -= (float)y0; sx -= (float)x0;
+            if (y0 < 0) { y0 = 0; sy = 0.f; }
+            if (x0 < 0) { x0 = 0; sx = 0.f; }
+            if (y0 >= a.src_h - 1) { y0 = a.src_h - 1; sy = 0.f; }
+            if (x0 >= a.src_w - 1) { x0 = a.src_w - 1; sx = 0.f; }
+            y1 = min(y0 + 1, a.src_h - 1); x1 = min(x0 + 1, a.src_w - 1);
         }
         for (int c = 0; c < a.nch; ++c) {
             const int sc = a.ch0 + ((a.flip_rgb && c < 3) ? 2 - c : c);
             float v;
             if (resize) {
-                const float top = src_at(a, y0, x0, sc) * (1.f - sx) + src_at(a, y0, x1, sc) * sx;
-                const float bot = src_at(a, y1, x0, sc) * (1.f - sx) + src_at(a, y1, x1, sc) * sx;
-                v = top * (1.f - sy) + bot * sy;
-                if (a.src_kind == 0) v = rintf(v);  // the reference resizes uint8 images to uint8
+                const double top = (double)src_at(a, y0, x0, sc) * (double)(1.f - sx) + (double)src_at(a, y0, x1, sc) * (double)sx;
+                const double bot = (double)src_at(a, y1, x0, sc) * (double)(1.f - sx) + (double)src_at(a, y1, x1, sc) * (double)sx;
+                v = (float)(top * (double)(1.f - sy) + bot * (double)sy);
+                if (a.src_kind == 0) v = rintf(v);  // uint8 in -> uint8 out (3-channel uint8 frames take the Pillow-exact kernel)
             } else {
                 v = src_at(a, y, x, sc);
             }

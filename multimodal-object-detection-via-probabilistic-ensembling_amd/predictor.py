@@ -60,10 +60,9 @@ class DefaultPredictor:
         img = np.asarray(img)
         if self.input_format == "RGB":
             img = img[:, :, ::-1]  # the caller hands BGR; the model was trained on RGB (defaults.py:188-190)
-        if img.dtype != np.uint8:
-            # 3-channel images go through Pillow as uint8 in the reference (transform.py:92-95: img.astype(np.uint8));
-            # the 4 / 6-channel fusion inputs stay floating point (cv2.resize branch, transform.py:82-91)
-            img = img.astype(np.uint8) if img.shape[2] == 3 else img.astype(np.float32)
+        # 3-channel images go through Pillow as uint8 in the reference (transform.py:92-95: img.astype(np.uint8));
+        # the 4 / 6-channel fusion inputs are floating point there (cv2.resize branch, transform.py:82-91)
+        img = img.astype(np.uint8, copy=False) if img.shape[2] == 3 else img.astype(np.float32, copy=False)
         return torch.from_numpy(np.ascontiguousarray(img)).to(self.model.device)
 
     def predict_batch(self, images):

@@ -12,7 +12,7 @@ tests/test_oracle_resize.py and tests/golden/pil_resize.npz:
   * horizontal pass over all source rows into a uint8 image, then the vertical pass (each pass rounds:
     (2^21 + sum) >> 22, clipped to 0..255).
 The 4- and 6-channel inputs go through cv2.resize on float64 in the reference (transform.py:82-91); OpenCV is not
-available here, so that branch stays a plain half-pixel bilinear (parity unpinned)."""
+available here: `cv2_linear_resize_f64` restates its published INTER_LINEAR rule, PARITY UNPINNED."""
 import math
 
 import numpy as np
@@ -79,3 +79,30 @@ def pil_bilinear_resize_u8(img, new_h, new_w):
     if new_h != h:
         out = _pass(out, *pil_bilinear_coeffs(h, new_h), axis=0)
     return out
+
+
+def cv2_linear_resize_f64(img, new_h, new_w):
+    """cv2.resize(img, (new_w, new_h)) with the default INTER_LINEAR on a floating-point [H, W, C] image - the
+    reference's branch for 4- and 6-channel inputs (transform.py:82-91).  PARITY UNPINNED: OpenCV (4.6.0 in
+    probEn.yml) is a third-party dependency that is neither in /root/reference nor installed here; this restates
+    the published algorithm of imgproc/resize.cpp (resizeGeneric_ / HResizeLinear / VResizeLinear for CV_64F):
+    fx = float((dx + 0.5) * scale - 0.5), sx = floor(fx), fx -= sx; taps left of the image or on / right of the last
+    column collapse onto the edge pixel; float32 weights (1 - fx, fx); horizontal then vertical pass in float64."""
+    img = np.asarray(img, dtype=np.float64)
+    h, w = img.shape[:2]
+
+    def taps(n_in, n_out):
+        scale = float(n_in) / float(n_out)
+        f = ((np.arange(n_out, dtype=np.float64) + 0.5) * scale - 0.5).astype(np.float32)
+        s = np.floor(f).astype(np.int64)
+        f = (f - s.astype(np.float32)).astype(np.float32)
+        lo = s < 0
+        s[lo], f[lo] = 0, 0.0
+        hi = s >= n_in - 1
+        s[hi], f[hi] = n_in - 1, 0.0
+        return s, np.minimum(s + 1, n_in - 1), (np.float32(1.0) - f).astype(np.float64), f.astype(np.float64)
+
+    x0, x1, ax0, ax1 = taps(w, new_w)
+    y0, y1, ay0, ay1 = taps(h, new_h)
+    rows = img[:, x0] * ax0[None, :, None] + img[:, x1] * ax1[None, :, None]          # horizontal pass
+    return rows[y0] * ay0[:, None, None] + rows[y1] * ay1[:, None, None]             # vertical pass

@@ -241,6 +241,22 @@ def rand_boxes(g, n, span=600.0, wh=120.0):
     return torch.cat([xy, xy + torch.rand(n, 2, generator=g) * wh + 1], 1)
 
 
+@pytest.mark.parametrize("case", [(48, 60, 75, 94, 4), (64, 64, 31, 47, 4), (90, 30, 135, 30, 3)])
+def test_preprocess_float_resize_vs_opencv_restatement(L, case):
+    """4- / 6-channel fusion inputs are floating point and go through cv2.resize in the reference; the kernel follows
+    the oracle's restatement of OpenCV's INTER_LINEAR rule exactly (that restatement itself is unpinned)."""
+    from oracle import resize as R
+    h, w, nh, nw, c = case
+    img = np.random.default_rng(h * w).integers(0, 256, size=(h, w, c)).astype(np.float32)
+    ph, pw = (nh + 31) // 32 * 32, (nw + 31) // 32 * 32
+    mean, std = [103.53, 116.28, 123.675, 135.438][:c], [1.0, 57.375, 2.0, 1.0][:c]
+    dst = torch.empty((ph, pw, 4), dtype=torch.float16, device="cuda")
+    L.preprocess_pack(torch.from_numpy(img).cuda(), dst, src_kind=1, ch0=0, nch=c, flip_rgb=False, dst_hw=(nh, nw), mean=mean, std=std)
+    inv = np.float32(1.0) / np.asarray(std, dtype=np.float32)
+    want = ((R.cv2_linear_resize_f64(img, nh, nw).astype(np.float32) - np.asarray(mean, dtype=np.float32)) * inv).astype(np.float16)
+    assert np.array_equal(dst.cpu().numpy()[:nh, :nw, :c], want)
+
+
 @pytest.mark.parametrize("case", [(2, 48, 60, 75, 94), (1, 64, 64, 31, 47), (1, 512, 640, 800, 1000), (3, 90, 30, 135, 30)])
 def test_preprocess_pil_exact_vs_oracle(L, case):
     """3-channel uint8 frames are resized exactly like Pillow (the reference's path, transform.py:92-97): every packed
