@@ -42,7 +42,10 @@ def parse():
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--conv-impl", type=int, default=2, help="1: register-staged conv kernel, 2: LDS-DMA conv kernel")
     ap.add_argument("--serial-detectors", action="store_true", help="run the two detectors back to back on one stream")
-    ap.add_argument("--stagger", type=int, default=0, help="N > 0: throughput mode, detector 2 trails detector 1 by its res<N> stage")
+    ap.add_argument("--stagger", type=int, default=3,
+                    help="N > 0 (default 3): throughput mode of the pipeline - detector 2 trails detector 1 by its res<N> stage and "
+                         "batches follow each other without a device-wide wait (all K timed steps still complete inside the "
+                         "timed region); 0: every step waits for its own fusion before the next one starts")
     ap.add_argument("--tile256", type=int, default=-1, help="conv tile policy override (pe_set_conv_tile256)")
     ap.add_argument("--layers", type=str, default="", help="write a per-conv-launch table (shape, ms, TFLOP/s) to this file")
     return ap.parse_args()
@@ -249,7 +252,9 @@ def main():
                                    f"R{args.depth}-FPN x2, 640x512 -> 800x1000 (padded 800x1024), K=3, random-init weights",
                        "batch_pairs_per_gpu": B, "detections_per_image_mean": round(n_det, 1),
                        "fused_rows_per_pair_mean": round(n_fused, 1),
-                       "end_to_end_tflops": round(value * GFLOP_PER_PAIR / 1e3, 1)},
+                       "end_to_end_tflops": round(value * GFLOP_PER_PAIR / 1e3, 1),
+                       "schedule": ("two detector streams, staggered by res%d, batches back to back" % args.stagger) if args.stagger > 0
+                                   and not args.serial_detectors else ("one stream" if args.serial_detectors else "two detector streams, step by step")},
         }
         if not args.no_roofline:
             # rank-local leg: no collective inside (the other ranks are already waiting at the final barrier)
