@@ -159,7 +159,7 @@ def roofline_leg(step, layers_path="", reps=10):
     out["method"] = ("avg_launch_ms = HIP-event timing of every distinct launch replayed back-to-back on the launch stream; "
                      "agrees with rocprofv3 --kernel-trace --stats of `bench.py --serial-detectors` "
                      "(profiles/r01_final_kernel_stats.csv).  In the default two-stream run co-running kernels stretch each "
-                     "other's durations 1.4-1.5x (profiles/r01_final_kernel_stats_two_streams.csv) while the step gets shorter.")
+                     "other's durations 1.5-1.8x (profiles/r01_final_kernel_stats_two_streams.csv) while the step gets shorter.")
     out["all_conv_variants"] = {k: {"launches": v[0], "gflop": round(v[1] / 1e9, 1), "ms": round(v[2] * 1e3, 3),
                                     "tflops": round(v[1] / v[2] / 1e12, 1), "algorithmic_gbs": round(v[3] / v[2] / 1e9, 0)}
                                 for k, v in sorted(agg.items(), key=lambda kv: -kv[1][2])}
