@@ -148,7 +148,9 @@ def roofline_leg(step, layers_path="", reps=10):
         key = d["kernel"].replace(" ", "")
         for k, v in traffic.items():
             if k.replace(" ", "") == key:
-                d["traffic"] = {"hbm_mbytes_per_launch": v["hbm_mb_per_launch"], "unit": "MB", "source": "rocprofv3 --pmc FETCH_SIZE(x2)+WRITE_SIZE, profiles/"}
+                d["traffic"] = round(v["hbm_mb_per_launch"] * 1e6)   # HBM bytes per launch (compare: algorithmic_mbytes_per_launch)
+                d["traffic_detail"] = {"hbm_mbytes_per_launch": v["hbm_mb_per_launch"], "unit": "MB",
+                                       "source": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE, separate passes, profiles/r01_pmc_traffic.json"}
         return d
     dom = max(agg, key=lambda k: agg[k][2])
     out = with_traffic(describe(dom))
