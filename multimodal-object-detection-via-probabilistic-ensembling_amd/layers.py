@@ -155,7 +155,8 @@ def conv2d_nhwc(x, weight, bias, *, kernel, stride=1, relu=False, residual=None,
         cin_real = 3 if kernel == 7 else Cin
         shape = f"N{N} {H}x{W} Cin{Cin} Cout{Cout} k{kernel} s{stride} res{residual_mode} f32{int(out_f32)}"
         M = N * Ho * Wo
-        nbytes = (N * H * W * (3 if kernel == 7 else Cin) * 2 + weight.numel() * 2 + M * (cout_store or Cout) * (4 if out_f32 else 2)
+        in_elems = M * Cin if kernel == 1 else N * H * W * (3 if kernel == 7 else Cin)   # a strided 1x1 reads only its samples
+        nbytes = (in_elems * 2 + weight.numel() * 2 + M * (cout_store or Cout) * (4 if out_f32 else 2)
                   + (M * Cout * 2 if residual_mode == 1 else (residual.numel() * 2 if residual_mode == 2 else 0)))
         PROFILE.append({"variant": variant, "shape": shape, "flops": 2.0 * N * Ho * Wo * Cout * kernel * kernel * cin_real,
                         "bytes": float(nbytes),
