@@ -111,23 +111,30 @@ int pe_conv2d_nhwc_f16(const void* input, const void* weight, const float* bias,
                        int32_t kernel, int32_t stride, int32_t relu, int32_t residual_mode,
                        int32_t res_h, int32_t res_w, int32_t out_f32, int32_t cout_store,
                        int32_t out_stride, void* stream);
-/* Implementation switch for A/B measurements: 1 = register-staged double-buffered kernel,
- * 2 (default) = LDS-DMA (global_load_lds) kernels incl. the kw-reuse 3x3 kernel, 3 = LDS-DMA kernels with the
- * generic (per-tap) 3x3.  The 7x7 stem always uses 1.  Process-global. */
+/* Implementation switch for A/B measurements (thread-safe: one relaxed atomic each; a change affects launches issued
+ * after it): 1 = register-staged double-buffered kernel, 2 (default) = LDS-DMA (global_load_lds) kernels incl. the
+ * kw-reuse 3x3 kernel, 3 = LDS-DMA kernels with the generic (per-tap) 3x3.  The 7x7 stem always uses 1. */
 int pe_set_conv_impl(int32_t impl);
-/* Measurement aid (results become WRONG): 0 = normal, 1 = skip the LDS-DMA loads, 2 = skip the MFMAs (kw-reuse 3x3
- * kernel and phase-split kernel), 3 = skip the fragment reads (phase-split kernel); bits 4-5 choose the phase-split
- * kernel's stagger partition.  Used by scripts/ablate_conv.py / scripts/ablate_p8.py only. */
-int pe_set_conv_ablation(int32_t mode);
-/* Kernel-selection policy bits (A/B measurements; default 41 = 1|8|32):
+/* Kernel-selection policy bits of pe_conv2d_nhwc_f16 (A/B measurements; default 9 = 1|8):
  *   1: 256-row block tiles (8 waves) for 3x3 launches with >= 512 such tiles     2: the same for 1x1 launches
  *   4: two-stage pipeline in the generic 1x1 kernel                              8: 256x256 two-stage kernel for long-K GEMMs
- *  16: 256x256 kernel for every eligible launch                                 32: double-buffered weight tile in the 3x3 kernel
- *  64: experimental 256x256 four-stage ring kernel (counted vmcnt, raw barriers) for every eligible launch
- * 128: experimental 256x256 phase-split kernel (quadrant phases, staggered wave rows, s_setprio) for every eligible launch
- * 256: experimental 512-row / 16-wave tiles in the kw-reuse 3x3 kernel
- * 1024: experimental 256x256 phase-split kernel on the kw-reuse slab (3x3 only) */
+ *  16: 256x256 kernel for every eligible launch */
 int pe_set_conv_tile256(int32_t mode);
+
+/* ---------------------------------------------------------------------------------------------
+ * "Weights-direct" 3x3 convolution (csrc/conv_wd.h): same reference rows as pe_conv2d_nhwc_f16 with kernel 3
+ * (layers/wrappers.py:62-98 + folded FrozenBatchNorm2d layers/batch_norm.py:45-65 + relu_; the 3x3 convolutions of
+ * backbone/resnet.py:205-221, backbone/fpn.py:127-137 and proposal_generator/rpn.py:74-85).
+ * The weights are packed ONCE into MFMA-fragment order (pe_conv_wd_pack_weights) and streamed L2 -> VGPR; only the
+ * pixels go through LDS.  Supported: stride 1 / pad 1, Cin % 64 == 0, Cout % 256 == 0, W % 32 == 0 with W | 128 or
+ * 128 | W, input < 4 GiB; everything else -> pe_conv2d_nhwc_f16.  Epilogue: + bias (required) + ReLU, fp16 NHWC
+ * output with row stride out_stride (0 = Cout).
+ * ------------------------------------------------------------------------------------------- */
+int pe_conv_wd_supported(int32_t kernel, int32_t stride, int32_t H, int32_t W, int32_t Cin, int32_t Cout);
+/* weight: [Cout][3][3][Cin] fp16 (the layout pe_conv2d_nhwc_f16 takes); packed: Cout*9*Cin halfs */
+int pe_conv_wd_pack_weights(const void* weight, void* packed, int32_t Cout, int32_t Cin, int32_t kernel, void* stream);
+int pe_conv3x3_wd_f16(const void* input, const void* packed_weight, const float* bias, void* output, int32_t N,
+                      int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t relu, int32_t out_stride, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Front-end layout kernels.

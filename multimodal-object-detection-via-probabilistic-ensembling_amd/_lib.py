@@ -18,8 +18,10 @@ SIGNATURES = {
     "pe_proben_fuse_batch": [c_void_p] * 8 + [c_int] * 5 + [c_double] * 3 + [c_void_p] * 5 + [c_void_p],
     "pe_conv2d_nhwc_f16": [c_void_p] * 5 + [c_int] * 14 + [c_void_p],
     "pe_set_conv_impl": [c_int],
-    "pe_set_conv_ablation": [c_int],
     "pe_set_conv_tile256": [c_int],
+    "pe_conv_wd_supported": [c_int] * 6,
+    "pe_conv_wd_pack_weights": [c_void_p] * 2 + [c_int] * 3 + [c_void_p],
+    "pe_conv3x3_wd_f16": [c_void_p] * 4 + [c_int] * 7 + [c_void_p],
     "pe_preprocess_pack": [c_void_p] + [c_int] * 11 + [c_void_p] * 4,
     "pe_preprocess_pack_batch": [c_void_p] + [c_int] * 12 + [c_void_p] * 4,
     "pe_preprocess_pack_pil_u8": [c_void_p] + [c_int] * 11 + [c_void_p] * 2 + [c_void_p, c_int, c_void_p, c_int] + [c_void_p] * 2,

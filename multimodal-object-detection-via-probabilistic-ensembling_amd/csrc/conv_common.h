@@ -1,5 +1,4 @@
-// Shared definitions of the LDS-DMA convolution kernels (conv_igemm2.hip: production kernels and dispatch;
-// conv_experimental.hip: the measured-but-not-dispatched 256 x 256 variants).  Internal linkage: every translation
+// Shared definitions of the LDS-DMA convolution kernels (conv_igemm2.hip: kernels and dispatch).  Internal linkage: every translation
 // unit gets its own copy of the helpers and of the 16-byte zero page.
 #pragma once
 #include <hip/hip_fp16.h>
@@ -21,7 +20,6 @@ struct Conv2Args {
     int resH, resW;
     int out_f32, cout_store, out_stride;
     int tiles_m, tiles_n;
-    int ablate;  // measurement only (pe_set_conv_ablation): 1 = skip the LDS-DMA loads, 2 = skip the MFMAs
 };
 }  // namespace pe
 using pe::Conv2Args;
@@ -218,9 +216,3 @@ __device__ __forceinline__ void epilogue256(const Conv2Args& a, float16v (&acc)[
 
 }  // namespace
 
-namespace pe {
-// experimental 256 x 256 kernels (conv_experimental.hip); mode3x3 selects the gather
-int launch_conv_ring(const Conv2Args& a, int mode3x3, hipStream_t st);
-int launch_conv_p8(const Conv2Args& a, int mode3x3, hipStream_t st);
-int launch_conv_p8r(const Conv2Args& a, hipStream_t st);
-}  // namespace pe

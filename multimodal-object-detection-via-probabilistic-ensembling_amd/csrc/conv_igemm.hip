@@ -18,6 +18,8 @@
 //   m-tiles (3x3 halo) sit on one XCD's L2.
 #include <hip/hip_fp16.h>
 
+#include <atomic>
+
 #include "common.h"
 
 namespace {
@@ -286,10 +288,9 @@ namespace pe {
 int conv2_dispatch(const void* in, const void* wgt, const float* bias, const void* res, void* out, int N, int H, int W,
                    int Cin, int Cout, int Ho, int Wo, int K, int M, int mode3x3, int stride, int relu, int res_mode,
                    int resH, int resW, int out_f32, int cout_store, int out_stride, hipStream_t st);
-extern int g_conv3x3_reuse;
-extern int g_conv_ablate;
-extern int g_conv_tile256;
-static int g_conv_impl = 2;  // 1: register-staged double-buffer kernel (this file); 2: LDS-DMA kernel (conv_igemm2.hip)
+extern std::atomic<int> g_conv3x3_reuse;
+extern std::atomic<int> g_conv_tile256;
+static std::atomic<int> g_conv_impl{2};  // 1: register-staged double-buffer kernel (this file); 2: LDS-DMA kernel (conv_igemm2.hip)
 }  // namespace pe
 
 extern "C" int pe_set_conv_impl(int impl) {
@@ -304,11 +305,6 @@ extern "C" int pe_set_conv_impl(int impl) {
 
 extern "C" int pe_set_conv_tile256(int mode) {
     pe::g_conv_tile256 = mode;
-    return PE_OK;
-}
-
-extern "C" int pe_set_conv_ablation(int mode) {
-    pe::g_conv_ablate = mode;
     return PE_OK;
 }
 

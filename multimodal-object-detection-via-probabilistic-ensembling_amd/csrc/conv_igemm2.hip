@@ -15,12 +15,9 @@
 //   * out-of-image taps (3x3 halo) and rows beyond M read a 16-byte zero page instead of branching;
 //   * 32 KiB of LDS per workgroup (+ a two-pass fp32 epilogue staging of 33 KiB that reuses it) lets 4
 //     workgroups share a CU, so one workgroup's DMA wait overlaps three others' MFMAs.
-#include "conv_common.h"
+#include <atomic>
 
-namespace pe {
-extern int g_conv_tile256;
-}
-using pe::g_conv_tile256;
+#include "conv_common.h"
 
 namespace {
 
@@ -169,138 +166,11 @@ __global__ __launch_bounds__(BM * 2, BM == 128 ? (STAGES == 1 ? 3 : 2) : (STAGES
 //     (output pixel m0 + j - 1) has oh + kh - 1 outside [0, H) or lies outside [0, M);
 //   * its two other users (kw = 0 / 2) either sit in the same image row (same validity) or are exactly the
 //     cases ow == 0 (kw = 0) / ow == W-1 (kw = 2), which are masked to zero on the A FRAGMENT (per lane).
-template <int BM, int BN, int ABL>
-__global__ __launch_bounds__(BM * 2, BM == 128 ? 3 : 4) void conv3x3r_kernel(Conv2Args a) {
-    constexpr int THREADS = BM * 2, WAVES = BM / 32;   // waves as (BM/64) x 2, each 64 x (BN/2)
-    constexpr int WM = 64, WN = BN / 2;
-    constexpr int TM = WM / 32, TN = WN / 32;
-    constexpr int SLAB_ROWS = BM + 8;         // BM + 2 rounded up to a multiple of 8
-    constexpr int LAST_GROUP = BM / 8;        // DMA group holding slab rows BM .. BM+7 (wave 0's extra one)
-    constexpr int B_INSTR = BN / 8 / WAVES;
-    constexpr int A_BYTES = SLAB_ROWS * ROW_B;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-
-    const int nwg = a.tiles_m * a.tiles_n;
-    int bid = blockIdx.x;
-    {
-        const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int tile_n = bid % a.tiles_n, tile_m = bid / a.tiles_n;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int lrow = lane >> 3, lp = lane & 7;
-
-    // slab DMA: wave w owns row groups 4w..4w+3, wave 0 also the last group (descriptors are recomputed per slab
-    // - once per three K-steps - instead of living in registers)
-    constexpr int A_INSTR = 5;
-    const _Float16* b_src[B_INSTR];
-#pragma unroll
-    for (int i = 0; i < B_INSTR; ++i) {
-        const int r = (wave * B_INSTR + i) * 8 + lrow;
-        const int n = n0 + r;
-        b_src[i] = (n < a.Cout) ? a.wgt + (size_t)n * a.K + (lp ^ ((r >> 1) & 7)) * 8 : nullptr;
-    }
-    const _Float16* zero = reinterpret_cast<const _Float16*>(g_zero_page);
-
-    // fragment rows and edge masks (per lane, per M sub-tile)
-    const int frow = lane & 31, fkh = lane >> 5;
-    bool not_left[TM], not_right[TM];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int m = m0 + wm * WM + i * 32 + frow;
-        const int ow = (m < a.M ? m : 0) % a.Wo;
-        not_left[i] = ow != 0;
-        not_right[i] = ow != a.Wo - 1;
-    }
-    const unsigned char* lb = smem + A_BYTES + (wn * WN + frow) * ROW_B;
-    const int fswb = (frow >> 1) & 7;
-
-    float16v acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-    const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-
-    const int chunks = a.Cin / BK;
-    for (int kh = 0; kh < 3; ++kh) {
-        for (int cc = 0; cc < chunks; ++cc) {
-            const int c0 = cc * BK;
-#pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-                if (kw == 0 && ABL != 1) {
-                    // ---- A slab for (kh, chunk): rows m0-1 .. m0+128 shifted by (kh-1) image rows ----
-#pragma unroll
-                    for (int i = 0; i < A_INSTR; ++i) {
-                        if (i == 4 && wave != 0) continue;  // wave-uniform
-                        const int g = i < 4 ? wave * 4 + i : LAST_GROUP;
-                        const int j = g * 8 + lrow;           // slab row
-                        const int m = m0 + j - 1;             // its centre user
-                        bool ok = m >= 0 && m < a.M && j < BM + 2;
-                        const int mm = ok ? m : 0;
-                        const int ih = (mm / a.Wo) % a.Ho + kh - 1;
-                        ok = ok && (unsigned)ih < (unsigned)a.H;
-                        const _Float16* p = ok ? a.in + (size_t)(mm + (kh - 1) * a.W) * a.Cin + c0 + (lp ^ ((j >> 1) & 7)) * 8 : zero;
-                        __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(smem + g * 1024), 16, 0, 0);
-                    }
-                }
-                // ---- weight tile of tap (kh, kw) ----
-                const int k0 = (kh * 3 + kw) * a.Cin + c0;
-#pragma unroll
-                for (int i = 0; i < (ABL == 1 ? 0 : B_INSTR); ++i) {
-                    const _Float16* p = b_src[i] ? b_src[i] + k0 : zero;
-                    __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(smem + A_BYTES + (wave * B_INSTR + i) * 1024), 16, 0, 0);
-                }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                // slab row of output row r for this tap = r + kw
-                const int arow0 = wm * WM + frow + kw;
-#pragma unroll
-                for (int ks = 0; ks < BK / 16; ++ks) {
-                    half8 af[TM], bf[TN];
-#pragma unroll
-                    for (int i = 0; i < TM; ++i) {
-                        const int r = arow0 + i * 32;
-                        const int ch = ((ks * 2 + fkh) ^ ((r >> 1) & 7)) << 4;
-                        af[i] = *reinterpret_cast<const half8*>(smem + r * ROW_B + ch);
-                        if (kw == 0) af[i] = not_left[i] ? af[i] : zero8;
-                        if (kw == 2) af[i] = not_right[i] ? af[i] : zero8;
-                    }
-                    const int chb = ((ks * 2 + fkh) ^ fswb) << 4;
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const half8*>(lb + j * 32 * ROW_B + chb);
-                    if (ABL == 2) {
-#pragma unroll
-                        for (int i = 0; i < TM; ++i)
-#pragma unroll
-                            for (int j = 0; j < TN; ++j) acc[i][j][0] += (float)af[i][0] + (float)bf[j][0];
-                        continue;
-                    }
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-#pragma unroll
-                        for (int j = 0; j < TN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
-                }
-                __syncthreads();
-            }
-        }
-    }
-    epilogue<BM, BN, THREADS>(a, acc, smem, m0, n0, tid, lane, wm, wn);
-}
-
-// Same kernel with the WEIGHT tile double-buffered: tap t+1's 16 KiB B tile streams into the other LDS stage while
-// tap t feeds the MFMAs, so per (kh, chunk) group only the A slab DMA is exposed and there are 4 barriers
-// instead of 6.  LDS: slab + 2 x 16 KiB (66 KiB at BM = 256: still two 8-wave workgroups per CU).
+// The WEIGHT tile is double-buffered: tap t+1's 16 KiB B tile streams into the other LDS stage while
+// tap t feeds the MFMAs, so per (kh, chunk) group only the A slab DMA is exposed (4 barriers per 3 taps).  LDS: slab + 2 x 16 KiB (66 KiB at BM = 256: still two 8-wave workgroups per CU).
 template <int BM, int BN>
 __global__ __launch_bounds__(BM * 2, BM == 128 ? 3 : 4) void conv3x3rb_kernel(Conv2Args a) {
-    static_assert(BM <= 512, "at most 16 waves");
-    constexpr int THREADS = BM * 2, WAVES = BM / 32;   // waves as (BM/64) x 2, each 64 x (BN/2)
+        constexpr int THREADS = BM * 2, WAVES = BM / 32;   // waves as (BM/64) x 2, each 64 x (BN/2)
     constexpr int WM = 64, WN = BN / 2;
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int SLAB_ROWS = BM + 8;         // BM + 2 rounded up to a multiple of 8
@@ -433,32 +303,20 @@ int launch3x3r(const Conv2Args& a0, hipStream_t st) {
     Conv2Args a = a0;
     a.tiles_m = pe::ceil_div(a.M, BM);
     a.tiles_n = pe::ceil_div(a.Cout, BN);
-    constexpr size_t stage = (size_t)(BM + 8 + BN) * ROW_B;
     constexpr size_t epi = (size_t)64 * (BN + 4) * 4;
-    constexpr size_t lds = stage > epi ? stage : epi;
+    constexpr size_t stage_b = (size_t)(BM + 8 + 2 * BN) * ROW_B;
+    constexpr size_t lds_b = stage_b > epi ? stage_b : epi;
     const dim3 grid(a.tiles_m * a.tiles_n), block(BM * 2);
-    if (a.ablate == 0 && (g_conv_tile256 & 32)) {
-        constexpr size_t stage_b = (size_t)(BM + 8 + 2 * BN) * ROW_B;
-        constexpr size_t lds_b = stage_b > epi ? stage_b : epi;
-        if (lds_b > 64 * 1024) {
-            static bool done = false;
-            if (!done) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3rb_kernel<BM, BN>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
-                done = true;
-            }
+    if (lds_b > 64 * 1024) {
+        static bool done = false;
+        if (!done) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3rb_kernel<BM, BN>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
+            done = true;
         }
-        hipLaunchKernelGGL((conv3x3rb_kernel<BM, BN>), grid, block, lds_b, st, a);
-        PE_CHECK_LAUNCH("pe_conv2d_nhwc_f16(3x3 row-reuse, B double-buffered)");
-        return PE_OK;
     }
-    if (a.ablate == 1)
-        hipLaunchKernelGGL((conv3x3r_kernel<BM, BN, 1>), grid, block, lds, st, a);
-    else if (a.ablate == 2)
-        hipLaunchKernelGGL((conv3x3r_kernel<BM, BN, 2>), grid, block, lds, st, a);
-    else
-        hipLaunchKernelGGL((conv3x3r_kernel<BM, BN, 0>), grid, block, lds, st, a);
-    PE_CHECK_LAUNCH("pe_conv2d_nhwc_f16(3x3 row-reuse)");
+    hipLaunchKernelGGL((conv3x3rb_kernel<BM, BN>), grid, block, lds_b, st, a);
+    PE_CHECK_LAUNCH("pe_conv2d_nhwc_f16(3x3 row-reuse, B double-buffered)");
     return PE_OK;
 }
 
@@ -621,12 +479,9 @@ int launch2(const Conv2Args& a0, hipStream_t st) {
 }  // namespace
 
 namespace pe {
-int g_conv_ablate = 0;
-int g_conv_tile256 = 41;  // bit 0: 256-row tiles for big 3x3 launches, bit 1: for big 1x1 launches, bit 2: two-stage 1x1 pipeline,
-                          // bit 3: 256x256 two-stage kernel for long-K GEMMs, bit 4: ... for every eligible launch,
-                          // bit 5: double-buffered weight tile in the kw-reuse 3x3 kernel, bit 6: 4-stage ring kernel,
-                          // bit 7: phase-split (staggered wave rows) 256x256 kernel - both experimental, see DESIGN.md 7
-int g_conv3x3_reuse = 1;  // pe_set_conv_impl(3) turns the kw-reuse 3x3 kernel off (A/B measurements)
+std::atomic<int> g_conv_tile256{9};   // bit 0: 256-row tiles for big 3x3 launches, bit 1: for big 1x1 launches, bit 2: two-stage 1x1 pipeline,
+                                      // bit 3: 256x256 two-stage kernel for long-K GEMMs, bit 4: ... for every eligible launch
+std::atomic<int> g_conv3x3_reuse{1};  // pe_set_conv_impl(3) turns the kw-reuse 3x3 kernel off (A/B measurements)
 // called from pe_conv2d_nhwc_f16 (conv_igemm.hip) for the 1x1 / 3x3 cases
 int conv2_dispatch(const void* in, const void* wgt, const float* bias, const void* res, void* out, int N, int H, int W,
                    int Cin, int Cout, int Ho, int Wo, int K, int M, int mode3x3, int stride, int relu, int res_mode,
@@ -635,39 +490,25 @@ int conv2_dispatch(const void* in, const void* wgt, const float* bias, const voi
     a.in = (const _Float16*)in; a.wgt = (const _Float16*)wgt; a.bias = bias; a.res = (const _Float16*)res; a.out = out;
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout; a.stride = stride; a.M = M; a.K = K;
     a.relu = relu; a.res_mode = res_mode; a.resH = resH; a.resW = resW; a.out_f32 = out_f32;
-    a.cout_store = cout_store; a.out_stride = out_stride; a.ablate = g_conv_ablate;
+    a.cout_store = cout_store; a.out_stride = out_stride;
+    const int policy = g_conv_tile256.load(std::memory_order_relaxed);
     const bool narrow = Cout <= 64;
     // 256 x 256 two-stage kernel: fp16 output, whole 256-channel tiles, a grid that fills the 256 CUs
     // (measured r01: +24 % on the K = 12544 FC GEMM, neutral-to-negative on the convolutions -> long-K GEMMs only;
     //  policy bit 4 forces it everywhere it applies, for A/B runs)
-    // experimental (policy bit 6): the 4-stage ring kernel for every eligible launch
-    // experimental (policy bit 10): phase-split 256 x 256 kernel with the kw-reuse slab for eligible 3x3 launches
-    if ((g_conv_tile256 & 1024) && mode3x3 && stride == 1 && !out_f32 && Cout % 256 == 0 && cout_store == Cout && Cin % 64 == 0 &&
-        (long long)pe::ceil_div(M, 256) * (Cout / 256) >= 224)
-        return launch_conv_p8r(a, st);
-    // experimental (policy bit 7): the phase-split 256 x 256 kernel for every eligible launch
-    if ((g_conv_tile256 & 128) && !out_f32 && Cout % 256 == 0 && cout_store == Cout && Cin % 64 == 0 &&
-        (long long)pe::ceil_div(M, 256) * (Cout / 256) >= 224)
-        return launch_conv_p8(a, mode3x3, st);
-    if ((g_conv_tile256 & 64) && !out_f32 && Cout % 256 == 0 && cout_store == Cout && Cin % 32 == 0 &&
-        (long long)pe::ceil_div(M, 256) * (Cout / 256) >= 224)
-        return launch_conv_ring(a, mode3x3, st);
-    if ((g_conv_tile256 & 8) && !out_f32 && Cout % 256 == 0 && cout_store == Cout &&
-        (long long)pe::ceil_div(M, 256) * (Cout / 256) >= 224 && ((g_conv_tile256 & 16) || (!mode3x3 && K >= 4096)))
+    if ((policy & 8) && !out_f32 && Cout % 256 == 0 && cout_store == Cout &&
+        (long long)pe::ceil_div(M, 256) * (Cout / 256) >= 224 && ((policy & 16) || (!mode3x3 && K >= 4096)))
         return mode3x3 ? launch_big<MODE_3X3>(a, st) : launch_big<MODE_1X1>(a, st);
-    if (mode3x3 && g_conv3x3_reuse) {
+    if (mode3x3 && g_conv3x3_reuse.load(std::memory_order_relaxed)) {
         if (narrow) return launch3x3r<128, 64>(a, st);
         // 256-row tiles (8 waves) halve the weight-tile traffic per flop; keep 128 when the grid would not fill the chip
-        const bool big = (g_conv_tile256 & 1) && (long long)pe::ceil_div(M, 256) * pe::ceil_div(Cout, 128) >= 512;
-        // experimental (policy bit 8): 512-row / 16-wave tiles - one workgroup per CU shares ONE weight tile per tap
-        if ((g_conv_tile256 & 256) && (g_conv_tile256 & 32) && (long long)pe::ceil_div(M, 512) * pe::ceil_div(Cout, 128) >= 512)
-            return launch3x3r<512, 128>(a, st);
+        const bool big = (policy & 1) && (long long)pe::ceil_div(M, 256) * pe::ceil_div(Cout, 128) >= 512;
         return big ? launch3x3r<256, 128>(a, st) : launch3x3r<128, 128>(a, st);
     }
     if (mode3x3) return narrow ? launch2<128, 64, MODE_3X3>(a, st) : launch2<128, 128, MODE_3X3>(a, st);
     if (narrow) return launch2<128, 64, MODE_1X1>(a, st);
-    const bool big1 = (g_conv_tile256 & 2) && (long long)pe::ceil_div(M, 256) * pe::ceil_div(Cout, 128) >= 512;
-    if (g_conv_tile256 & 4) return big1 ? launch2<256, 128, MODE_1X1, 2>(a, st) : launch2<128, 128, MODE_1X1, 2>(a, st);
+    const bool big1 = (policy & 2) && (long long)pe::ceil_div(M, 256) * pe::ceil_div(Cout, 128) >= 512;
+    if (policy & 4) return big1 ? launch2<256, 128, MODE_1X1, 2>(a, st) : launch2<128, 128, MODE_1X1, 2>(a, st);
     return big1 ? launch2<256, 128, MODE_1X1>(a, st) : launch2<128, 128, MODE_1X1>(a, st);
 }
 }  // namespace pe

@@ -1,0 +1,320 @@
+// "Weights-direct" convolution kernels for gfx950 (third generation).
+//
+// Replaces, per layer, the same reference rows as csrc/conv_igemm2.hip (layers/wrappers.py:62-98 Conv2d.forward +
+// layers/batch_norm.py:45-65 FrozenBatchNorm2d folded + relu_; backbone/resnet.py:205-221, backbone/fpn.py:127-137,
+// proposal_generator/rpn.py:74-85).
+//
+// What the round-1 measurements said: every LDS-staged variant ends LDS-port bound - per 256x256x64
+// step the LDS absorbs 64 KiB of DMA writes at ~64 B/clk plus 192 KiB of fragment reads against 2048 clk of MFMA.
+// The weight tile is the larger half of that traffic although weights are STATIC.  So here:
+//   * weights never touch LDS.  They are pre-packed ONCE (pe_conv_wd_pack_weights) in MFMA A-fragment order:
+//     one 1 KiB record per (32 output channels, 16 K) = exactly what one wavefront `global_load_dwordx4` reads,
+//     perfectly coalesced, straight into the VGPRs the MFMA consumes, DEPTH K-steps ahead (L2-resident stream);
+//   * only the pixels go through LDS, as a "slab" with EXPLICIT zero halo entries: entry e of an image-row segment
+//     holds input pixel (col - 1 + e), so the three kw taps are the SAME slab read at entry offsets 0 / 1 / 2 with
+//     no per-lane edge masks, and one slab serves a whole (kh, 64-channel chunk) group = 12 K-steps of 16;
+//   * slab rows are padded to 144 B (36 dwords): every ds_read_b128 of a fragment is bank-conflict-free and
+//     (kw, ks) become IMMEDIATE offsets of the read - no address VALU in the loop;
+//   * slab filling is register-staged (global_load_dwordx4 -> VGPR -> ds_write_b128), a group ahead, into a
+//     three-deep LDS ring: one barrier per 12 K-steps, and it is never on the read path;
+//   * the MFMA is issued as D[cout][pixel] = W[cout][k] * X[k][pixel] with the 32 output channels of a record
+//     PERMUTED so that a lane's 32 accumulator registers are 32 CONSECUTIVE output channels of one pixel: the
+//     epilogue is bias (folded into the accumulator init) + ReLU + four 16-byte stores per pixel block, straight
+//     from registers - no LDS transposition, no epilogue barriers.
+// Per wave: 128 pixels x 64 output channels (TPX = 4 pixel blocks x 2 channel blocks, 128 accumulator VGPRs), per
+// K-step of 16: 2 weight loads + 4 ds_read_b128 + 8 MFMA 32x32x16.  LDS traffic per MFMA is 1/4 of the 256x256
+// LDS-staged tile's; the texture path carries 32 B/clk/CU of weight stream instead.
+#pragma once
+#include <hip/hip_fp16.h>
+
+#include "common.h"
+
+namespace pe {
+struct ConvWdArgs {
+    const _Float16* in;    // NHWC fp16
+    const _Float16* wpk;   // packed weights (pe_conv_wd_pack_weights)
+    const float* bias;     // [Cout] or null
+    const _Float16* res;   // residual (1x1 kernels), NHWC fp16, or null
+    _Float16* out;
+    int N, H, W, Cin, Cout;
+    int M;           // N * H * W output pixels (3x3 stride 1 / 1x1 stride 1)
+    int relu;
+    int out_stride;  // halfs between output pixels
+    int seg, nseg;   // image-row segment length of a block tile and segments per tile
+    int tiles_m, tiles_n;
+};
+}  // namespace pe
+
+namespace wd {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float float16v __attribute__((ext_vector_type(16)));
+
+constexpr int SLAB_ROW_B = 144;  // 128 B of channels + 16 B pad: rows r .. r+15 hit 16 distinct 4-bank groups
+
+__device__ __attribute__((aligned(16))) static unsigned int g_zero16[4] = {0, 0, 0, 0};
+
+// Host-side mirror of the packed layout (used by the packing kernel and by tests):
+// record index = ((tile_n * KSEQ + kseq) * WN + wn) * 2 + blk, 512 halfs each; lane l holds
+// W[cout(l & 31)][k0 + 8 * (l >> 5) .. + 8] with cout = tile_n * WN * 64 + wn * 64 + perm(blk, l & 31).
+__host__ __device__ inline int cout_perm(int blk, int rho) {
+    return ((rho >> 2) & 1) * 32 + blk * 16 + (rho >> 3) * 4 + (rho & 3);
+}
+// K order of the 3x3 kernel: group g = (channel chunk cc outer, kernel row kh inner), then kw, then ks (16 wide)
+__host__ __device__ inline int k3x3_of_kseq(int kseq, int Cin, int e) {
+    const int g = kseq / 12, t = kseq - g * 12;
+    const int cc = g / 3, kh = g - cc * 3, kw = t / 4, ks = t - kw * 4;
+    return (kh * 3 + kw) * Cin + cc * 64 + ks * 16 + e;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// 3x3, stride 1, pad 1.  Block = WM x WN waves; wave (wm, wn) owns pixels [wm*TPX*32, +TPX*32) x channels [wn*64, +64).
+// ------------------------------------------------------------------------------------------------------
+// ABL (measurement builds only, results wrong): 1 = no weight loads in the loop, 2 = no LDS fragment reads in the loop,
+// 4 = no slab traffic and no barrier in the loop
+template <int WM, int WN, int TPX, int DEPTH, int ABL = 0>
+__global__ __launch_bounds__(64 * WM * WN, (TPX <= 4 ? 2 : 1)) void conv3x3_wd_kernel(pe::ConvWdArgs a) {
+    constexpr int THREADS = 64 * WM * WN;
+    constexpr int BPX = WM * TPX * 32;                  // pixels per block tile
+    constexpr int EMAX = BPX + BPX / 16;                // slab entries when every segment is 32 pixels
+    constexpr int NP = (EMAX * 8 + THREADS - 1) / THREADS;  // 16-byte slab pieces per thread
+    static_assert(12 % DEPTH == 0, "weight prefetch depth must divide the 12 K-steps of a group");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int nwg = a.tiles_m * a.tiles_n;
+    int bid = blockIdx.x;
+    {   // bijective XCD remap: each XCD (private L2) gets a contiguous run of tiles
+        const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_n = bid % a.tiles_n, tile_m = bid / a.tiles_n;
+    const int m0 = tile_m * BPX, n0 = tile_n * (WN * 64);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int segp = a.seg + 2;
+    const int E = a.nseg * segp;
+    const int slab_bytes = E * SLAB_ROW_B;
+
+    // ---- slab pieces owned by this thread: BYTE offset of the centre-row source (or -1) and its image row ----
+    // (pieces beyond the slab write to a private 16-byte dummy slot behind the ring: no divergent branches;
+    //  invalid sources - halo columns, rows above / below the image, pixels beyond M - use an out-of-range buffer
+    //  offset: the hardware bounds check of buffer_load returns zeros)
+    int p_off[NP], p_h[NP], p_lds[NP];
+#pragma unroll
+    for (int n = 0; n < NP; ++n) {
+        const int q = tid + n * THREADS;
+        const int e = q >> 3, c = q & 7;
+        p_off[n] = -1; p_h[n] = 0; p_lds[n] = 3 * slab_bytes + tid * 16;
+        if (e < E) {
+            const int s = e / segp, jj = e - s * segp - 1;
+            const int P0 = m0 + s * a.seg;
+            const int row = P0 / a.W, col = P0 - row * a.W + jj;
+            p_lds[n] = e * SLAB_ROW_B + c * 16;
+            p_h[n] = row % a.H;
+            if (P0 < a.M && (unsigned)col < (unsigned)a.W) p_off[n] = ((P0 + jj) * a.Cin + c * 8) * 2;
+        }
+    }
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.in), 0, a.M * a.Cin * 2, 0x00020000);
+    half8 sreg[NP];
+    auto slab_load1 = [&](int n, int g) {   // piece n of group g = (cc, kh): global -> registers
+        const int cc = g / 3, kh = g - cc * 3;
+        const int shift = ((kh - 1) * a.W * a.Cin + cc * 64) * 2;
+        const bool ok = p_off[n] >= 0 && (unsigned)(p_h[n] + kh - 1) < (unsigned)a.H;
+        const unsigned vo = ok ? (unsigned)(p_off[n] + shift) : 0xFFFFFFF0u;
+        sreg[n] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rin, vo, 0, 0));
+    };
+    auto slab_store1 = [&](int n, int buf) {  // registers -> LDS ring slot (the dummy slots are never read)
+        *reinterpret_cast<half8*>(smem + (p_lds[n] < 3 * slab_bytes ? buf * slab_bytes : 0) + p_lds[n]) = sreg[n];
+    };
+
+    // ---- fragment read bases: pixel block i of this wave, entry of tap kw = 0 ----
+    int fb[TPX];
+#pragma unroll
+    for (int i = 0; i < TPX; ++i) {
+        const int p = (wm * TPX + i) * 32;
+        const int s = p / a.seg, j0 = p - s * a.seg;
+        fb[i] = (s * segp + j0 + (lane & 31)) * SLAB_ROW_B + (lane >> 5) * 16;
+    }
+
+    // ---- weight stream: record pair (blk 0, 1) of K-step kseq for this wave: scalar offset + lane * 16 ----
+    const int G = 3 * (a.Cin / 64);
+    const int KSEQ = G * 12;
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.wpk), 0, a.Cout * a.Cin * 18, 0x00020000);
+    const int w_base = (tile_n * KSEQ * WN + wn) * 2048;
+    half8 wf[DEPTH][2];
+    auto w_load = [&](int slot, int kseq) {
+        const int ks = kseq < KSEQ ? kseq : KSEQ - 1;   // tail prefetches re-read the last record (unused)
+        const int so = w_base + ks * (WN * 2048);
+        wf[slot][0] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16, so, 0));
+        wf[slot][1] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16 + 1024, so, 0));
+    };
+
+    // ---- accumulators, initialised with the bias: lane holds channels n0 + wn*64 + (lane>>5)*32 + blk*16 + r ----
+    float16v acc[2][TPX];
+    {
+        const float* bp = a.bias + n0 + wn * 64 + (lane >> 5) * 32;
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            float16v b;
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const float4 v = *reinterpret_cast<const float4*>(bp + blk * 16 + r4 * 4);
+                b[r4 * 4 + 0] = v.x; b[r4 * 4 + 1] = v.y; b[r4 * 4 + 2] = v.z; b[r4 * 4 + 3] = v.w;
+            }
+#pragma unroll
+            for (int i = 0; i < TPX; ++i) acc[blk][i] = b;
+        }
+    }
+
+    // ---- prologue: slabs 0 and 1 into the ring, weight ring primed ----
+#pragma unroll
+    for (int n = 0; n < NP; ++n) slab_load1(n, 0);
+#pragma unroll
+    for (int n = 0; n < NP; ++n) slab_store1(n, 0);
+#pragma unroll
+    for (int n = 0; n < NP; ++n) slab_load1(n, G > 1 ? 1 : 0);
+#pragma unroll
+    for (int n = 0; n < NP; ++n) slab_store1(n, 1);
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) w_load(d, d);
+    __syncthreads();
+
+    half8 pf[2][TPX];
+    int cur = 0;  // ring slot of group g
+#pragma unroll
+    for (int i = 0; i < TPX; ++i) pf[0][i] = *reinterpret_cast<const half8*>(smem + fb[i]);
+
+    static_assert(NP <= 6, "slab pieces are spread over the 12 K-steps of a group");
+    for (int g = 0; g < G; ++g) {
+        const int nxt = cur == 2 ? 0 : cur + 1;
+        const int nn = nxt == 2 ? 0 : nxt + 1;
+        // slab g+2: piece n is loaded global -> registers in K-step n and stored registers -> ring slot nn in K-step
+        // 12 - NP + n of the same group (one basic block: the compiler counts vmcnt exactly).  Slot nn was last read in
+        // group g-1 and every wave has passed that barrier.
+        const int gl = g + 2 < G ? g + 2 : G - 1;
+        const unsigned char* sb = smem + cur * slab_bytes;
+        const unsigned char* sn = smem + nxt * slab_bytes;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 12; ++t) {
+            if (!(ABL & 4) && t < NP) slab_load1(t, gl);
+            // next step's pixel fragments (step 0 of the next group comes from the next ring slot, published by the
+            // barrier at the end of group g-1)
+            if (ABL & 2) {
+            } else if (t + 1 < 12) {
+                const int kw1 = (t + 1) / 4, ks1 = (t + 1) - kw1 * 4;
+#pragma unroll
+                for (int i = 0; i < TPX; ++i)
+                    pf[(t + 1) & 1][i] = *reinterpret_cast<const half8*>(sb + fb[i] + kw1 * SLAB_ROW_B + ks1 * 32);
+            } else {
+#pragma unroll
+                for (int i = 0; i < TPX; ++i) pf[(t + 1) & 1][i] = *reinterpret_cast<const half8*>(sn + fb[i]);
+            }
+            const int slot = t % DEPTH;
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                for (int i = 0; i < TPX; ++i)
+                    acc[blk][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[slot][blk], pf[t & 1][i], acc[blk][i], 0, 0, 0);
+            if (!(ABL & 1)) w_load(slot, g * 12 + t + DEPTH);
+            if (!(ABL & 4) && t >= 12 - NP) slab_store1(t - (12 - NP), nn);
+            // issue order inside the step: the MFMAs of blk 0 carry the next step's LDS reads in their shadows, the
+            // MFMAs of blk 1 carry the weight loads (whose ring slot blk 0 / blk 1 have just released), the slab piece
+            // load and the slab piece store
+#pragma unroll
+            for (int i = 0; i < TPX; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // VMEM read
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // (slab piece load, steps 0 .. NP-1)
+            __builtin_amdgcn_sched_group_barrier(0x008, TPX - 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      // (slab piece store, last NP steps)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (!(ABL & 4)) __syncthreads();  // publishes slab g+2, retires the reads of slab g
+        cur = nxt;
+    }
+
+    // ---- epilogue: ReLU + fp16, 64 contiguous bytes per lane and pixel block ----
+    if (a.relu) {
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int i = 0; i < TPX; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[blk][i][r] = fmaxf(acc[blk][i][r], 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < TPX; ++i) {
+        const int m = m0 + (wm * TPX + i) * 32 + (lane & 31);
+        if (m >= a.M) continue;
+        _Float16* o = a.out + (size_t)m * a.out_stride + n0 + wn * 64 + (lane >> 5) * 32;
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                half8 v;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (_Float16)acc[blk][i][hh * 8 + e];
+                *reinterpret_cast<half8*>(o + blk * 16 + hh * 8) = v;
+            }
+    }
+}
+
+// packing: [Cout][3][3][Cin] (or [Cout][K] for 1x1 with order = 0) -> fragment records
+__global__ void pack_weights_kernel(const _Float16* w, _Float16* out, int Cout, int K, int Cin, int WN, int is3x3) {
+    // one thread per 16-byte lane slot
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int KSEQ = K / 16;
+    const long long total = (long long)(Cout / 32) * KSEQ * 64;
+    if (idx >= total) return;
+    const int lane = (int)(idx & 63);
+    long long rec = idx >> 6;
+    const int blk = (int)(rec & 1); rec >>= 1;
+    const int wn = (int)(rec % WN); rec /= WN;
+    const int kseq = (int)(rec % KSEQ);
+    const int tile_n = (int)(rec / KSEQ);
+    const int cout = tile_n * WN * 64 + wn * 64 + cout_perm(blk, lane & 31);
+    const int e0 = (lane >> 5) * 8;
+    half8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int k = is3x3 ? k3x3_of_kseq(kseq, Cin, e0 + e) : kseq * 16 + e0 + e;
+        v[e] = w[(size_t)cout * K + k];
+    }
+    *reinterpret_cast<half8*>(out + idx * 8) = v;
+}
+
+// geometry the 3x3 kernel supports for a block tile of BPX pixels
+inline bool wd3x3_geometry(int W, int BPX, int* seg, int* nseg) {
+    if (W % 32) return false;
+    const int s = W < BPX ? W : BPX;
+    if (W % s || BPX % s) return false;
+    *seg = s; *nseg = BPX / s;
+    return true;
+}
+
+template <int WM, int WN, int TPX, int DEPTH, int ABL = 0>
+int launch_conv3x3_wd(pe::ConvWdArgs a, hipStream_t st) {
+    constexpr int BPX = WM * TPX * 32;
+    if (!wd3x3_geometry(a.W, BPX, &a.seg, &a.nseg)) return PE_ERR_UNSUPPORTED;
+    a.tiles_m = pe::ceil_div(a.M, BPX);
+    a.tiles_n = a.Cout / (WN * 64);
+    const size_t lds = (size_t)3 * a.nseg * (a.seg + 2) * SLAB_ROW_B + (size_t)64 * WM * WN * 16;
+    static bool done = false;
+    if (!done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wd_kernel<WM, WN, TPX, DEPTH, ABL>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        done = true;
+    }
+    hipLaunchKernelGGL((conv3x3_wd_kernel<WM, WN, TPX, DEPTH, ABL>), dim3(a.tiles_m * a.tiles_n), dim3(64 * WM * WN), lds, st, a);
+    return PE_OK;
+}
+
+}  // namespace wd

@@ -1,0 +1,56 @@
+// C-ABI of the weights-direct convolution kernels (csrc/conv_wd.h): packing, support query, launch.
+#include "conv_wd.h"
+
+namespace {
+
+// channel split of a block: WN waves x 64 output channels
+inline int wd_wn(int Cout) { return Cout % 256 == 0 ? 4 : 0; }
+
+}  // namespace
+
+extern "C" int pe_conv_wd_supported(int32_t kernel, int32_t stride, int32_t H, int32_t W, int32_t Cin, int32_t Cout) {
+    if (kernel != 3 || stride != 1) return 0;
+    if (Cin % 64 || Cin <= 0 || wd_wn(Cout) == 0 || H <= 0) return 0;
+    int seg, nseg;
+    return wd::wd3x3_geometry(W, 128, &seg, &nseg) ? 1 : 0;
+}
+
+extern "C" int pe_conv_wd_pack_weights(const void* weight, void* packed, int32_t Cout, int32_t Cin, int32_t kernel,
+                                       void* stream) {
+    PE_CHECK_ARG(weight && packed, "pe_conv_wd_pack_weights: null pointer");
+    PE_CHECK_ARG(kernel == 3, "pe_conv_wd_pack_weights: kernel %d not supported (3x3 only)", kernel);
+    PE_CHECK_ARG(Cin > 0 && Cin % 64 == 0 && wd_wn(Cout) != 0,
+                 "pe_conv_wd_pack_weights: needs Cin %% 64 == 0 and Cout %% 256 == 0 (got %d, %d)", Cin, Cout);
+    const int K = 9 * Cin;
+    const long long total = (long long)(Cout / 32) * (K / 16) * 64;
+    hipLaunchKernelGGL(wd::pack_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const _Float16*)weight, (_Float16*)packed, Cout, K, Cin, wd_wn(Cout), 1);
+    PE_CHECK_LAUNCH("pe_conv_wd_pack_weights");
+    return PE_OK;
+}
+
+extern "C" int pe_conv3x3_wd_f16(const void* input, const void* packed_weight, const float* bias, void* output,
+                                 int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t relu,
+                                 int32_t out_stride, void* stream) {
+    PE_CHECK_ARG(input && packed_weight && bias && output, "pe_conv3x3_wd_f16: null pointer (bias is required)");
+    PE_CHECK_ARG(N > 0 && H > 0 && W > 0, "pe_conv3x3_wd_f16: bad dims");
+    if (!pe_conv_wd_supported(3, 1, H, W, Cin, Cout)) {
+        pe::set_error("pe_conv3x3_wd_f16: geometry not supported (W %d, Cin %d, Cout %d): use pe_conv2d_nhwc_f16", W, Cin, Cout);
+        return PE_ERR_UNSUPPORTED;
+    }
+    const long long M = (long long)N * H * W;
+    PE_CHECK_ARG(M * Cin * 2 < (1ll << 32) && M < (1ll << 31), "pe_conv3x3_wd_f16: input larger than 4 GiB");
+    const int os = out_stride > 0 ? out_stride : Cout;
+    PE_CHECK_ARG(os % 8 == 0, "pe_conv3x3_wd_f16: out_stride must be a multiple of 8");
+    pe::ConvWdArgs a{};
+    a.in = (const _Float16*)input; a.wpk = (const _Float16*)packed_weight; a.bias = bias; a.res = nullptr;
+    a.out = (_Float16*)output; a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.M = (int)M; a.relu = relu;
+    a.out_stride = os;
+    const int st = wd::launch_conv3x3_wd<1, 4, 4, 4>(a, (hipStream_t)stream);
+    if (st != PE_OK) {
+        pe::set_error("pe_conv3x3_wd_f16: unsupported geometry");
+        return st;
+    }
+    PE_CHECK_LAUNCH("pe_conv3x3_wd_f16");
+    return PE_OK;
+}

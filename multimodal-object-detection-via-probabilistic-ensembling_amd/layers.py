@@ -160,9 +160,43 @@ def conv2d_nhwc(x, weight, bias, *, kernel, stride=1, relu=False, residual=None,
                   + (M * Cout * 2 if residual_mode == 1 else (residual.numel() * 2 if residual_mode == 2 else 0)))
         PROFILE.append({"variant": variant, "shape": shape, "flops": 2.0 * N * Ho * Wo * Cout * kernel * kernel * cin_real,
                         "bytes": float(nbytes),
-                        "args": (x, weight, bias, residual, out, dict(kernel=kernel, stride=stride, relu=relu,
-                                 residual_mode=residual_mode, out_f32=out_f32, cout_store=cout_store,
-                                 out_stride=out_stride, cout=cout))})
+                        "replay": (lambda: conv2d_nhwc(x, weight, bias, kernel=kernel, stride=stride, relu=relu, residual=residual,
+                                                       residual_mode=residual_mode, out=out, out_f32=out_f32,
+                                                       cout_store=cout_store, out_stride=out_stride, cout=cout))})
+    return out
+
+
+def conv_wd_supported(kernel, stride, H, W, Cin, Cout):
+    """True when the weights-direct kernel (csrc/conv_wd.h) takes this geometry."""
+    return bool(_lib.lib().pe_conv_wd_supported(int(kernel), int(stride), int(H), int(W), int(Cin), int(Cout)))
+
+
+def conv_wd_pack(weight):
+    """[Cout,3,3,Cin] fp16 device tensor -> the fragment-ordered copy pe_conv3x3_wd_f16 streams (same size)."""
+    _lib.require_cuda(weight)
+    Cout, kh, kw, Cin = weight.shape
+    assert kh == 3 and kw == 3 and weight.dtype == torch.float16 and weight.is_contiguous()
+    packed = torch.empty(Cout * 9 * Cin, dtype=torch.float16, device=weight.device)
+    _lib.check(_lib.lib().pe_conv_wd_pack_weights(_lib.ptr(weight), _lib.ptr(packed), Cout, Cin, 3, _lib.stream()),
+               "pe_conv_wd_pack_weights")
+    return packed
+
+
+def conv3x3_wd(x, packed, bias, cout, *, relu=False, out=None, out_stride=0):
+    """3x3 / stride 1 / pad 1 through the weights-direct kernel.  x [N,H,W,Cin] fp16 NHWC, packed = conv_wd_pack(w),
+    bias fp32 [cout] (required).  Returns [N,H,W,out_stride or cout] fp16."""
+    _lib.require_cuda(x, packed, bias)
+    N, H, W, Cin = x.shape
+    if out is None:
+        out = torch.empty((N, H, W, out_stride or cout), dtype=torch.float16, device=x.device)
+    st = _lib.lib().pe_conv3x3_wd_f16(_lib.ptr(x), _lib.ptr(packed), _lib.ptr(bias), _lib.ptr(out), N, H, W, Cin, cout,
+                                      int(relu), int(out_stride), _lib.stream())
+    _lib.check(st, "pe_conv3x3_wd_f16")
+    if PROFILE is not None:
+        M = N * H * W
+        PROFILE.append({"variant": "conv3x3_wd_kernel<1, 4, 4, 4, 0>", "shape": f"N{N} {H}x{W} Cin{Cin} Cout{cout} k3 s1 res0 f320",
+                        "flops": 2.0 * M * cout * 9 * Cin, "bytes": float(M * Cin * 2 + cout * 9 * Cin * 2 + M * cout * 2),
+                        "replay": (lambda: conv3x3_wd(x, packed, bias, cout, relu=relu, out=out, out_stride=out_stride))})
     return out
 
 

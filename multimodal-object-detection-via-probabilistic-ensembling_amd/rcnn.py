@@ -78,6 +78,7 @@ class GeneralizedRCNN:
         self._cells = (ctypes.c_float * (len(cfg.anchor_sizes) * 12))(*cell_anchor_table(cfg.anchor_sizes, cfg.aspect_ratios))
         self._reg_w = (ctypes.c_float * 4)(10.0, 10.0, 5.0, 5.0)
         self.training = False
+        self.use_wd = True   # weights-direct 3x3 kernel where the geometry allows (A/B switch)
 
     def eval(self):
         return self
@@ -85,6 +86,10 @@ class GeneralizedRCNN:
     # ------------------------------------------------------------------ stages
     def _conv(self, x, name, **kw):
         w, b = self.w.convs[name]
+        if kw.get("kernel") == 3 and name in self.w.wd and self.use_wd and kw.get("residual") is None \
+                and L.conv_wd_supported(3, 1, x.shape[1], x.shape[2], x.shape[3], w.shape[0]):
+            return L.conv3x3_wd(x, self.w.wd[name], b, w.shape[0], relu=kw.get("relu", False), out=kw.get("out"),
+                                out_stride=kw.get("out_stride", 0))
         return L.conv2d_nhwc(x, w, b, **kw)
 
     def _bottom_up(self, x, prefix):

@@ -73,6 +73,7 @@ class PackedDetector:
         self.num_classes = num_classes if num_classes is not None else ncls
         assert self.num_classes == ncls, (self.num_classes, ncls)
         self.convs = {}
+        self.wd = {}   # name -> fragment-ordered copy of a 3x3 weight for the weights-direct kernel (csrc/conv_wd.h)
         self._pack_backbone(sd, "backbone")
         if self.has_backbone_2:
             self._pack_backbone(sd, "backbone_2")
@@ -102,6 +103,17 @@ class PackedDetector:
         self.predictor = (torch.cat(pw, 0).half().contiguous().to(dev), torch.cat(pb, 0).to(dev))
         self.head_cols = 5 * self.num_classes + 2
         self.head_stride = (self.head_cols + 7) // 8 * 8
+        self._pack_wd()
+
+    def _pack_wd(self):
+        """Second, fragment-ordered copy of every 3x3 weight the weights-direct kernel can take (Cin % 64 == 0,
+        Cout % 256 == 0); whether a launch uses it depends on the feature-map width (layers.conv_wd_supported)."""
+        if self.device.type != "cuda":
+            return
+        from . import layers as L
+        for name, (w, b) in self.convs.items():
+            if w.dim() == 4 and w.shape[1] == 3 and w.shape[2] == 3 and w.shape[3] % 64 == 0 and w.shape[0] % 256 == 0 and b is not None:
+                self.wd[name] = L.conv_wd_pack(w)
 
     def _pack_backbone(self, sd, prefix):
         dev = self.device

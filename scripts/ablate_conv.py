@@ -1,5 +1,4 @@
-"""Ablation of the dominant kernel (3x3, 256->256 at 50x64, batch 32 = res4 conv2): how much of its time
-is LDS-DMA (global_load_lds) wait vs MFMA + fragment reads.  Usage (GPU box): python scripts/ablate_conv.py"""
+"""A/B of the conv kernel families on representative layer shapes (post-ReLU inputs).  Usage (GPU box): python scripts/ablate_conv.py"""
 import os
 import sys
 
@@ -27,21 +26,23 @@ def main():
     shapes = [(32, 200, 256, 256, 256, 3), (32, 50, 64, 256, 256, 3), (32, 100, 128, 256, 256, 3), (32, 50, 64, 1024, 256, 1),
               (32, 50, 64, 256, 1024, 1), (32000, 1, 1, 12544, 1024, 1)]
     for (N, H, W, Cin, Cout, k) in shapes:
-        x = torch.randn(N, H, W, Cin, device="cuda").half()
+        x = torch.randn(N, H, W, Cin, device="cuda").half().relu()
         w = (torch.randn(Cout, k, k, Cin, device="cuda") / (Cin * k * k) ** 0.5).half()
         b = torch.randn(Cout, device="cuda")
         out = torch.empty(N, H, W, Cout, device="cuda", dtype=torch.float16)
         fl = 2.0 * N * H * W * Cout * k * k * Cin
         row = []
-        for impl, abl, tile in [(1, 0, 1), (3, 0, 1), (2, 0, 0), (2, 0, 1), (2, 0, 3), (2, 0, 33), (2, 0, 25), (2, 0, 128), (2, 0, 41 | 1024)]:
+        for impl, tile in [(1, 1), (3, 1), (2, 0), (2, 1), (2, 3), (2, 9), (2, 25)]:
             lib.pe_set_conv_impl(impl)
-            lib.pe_set_conv_ablation(abl)
             lib.pe_set_conv_tile256(tile)
             ms = timeit(lambda: L.conv2d_nhwc(x, w, b, kernel=k, relu=True, out=out))
-            row.append(f"i{impl}a{abl}t{tile}: {ms:.4f}ms {fl / ms / 1e9:6.0f}TF")
+            row.append(f"i{impl}t{tile}: {ms:.4f}ms {fl / ms / 1e9:6.0f}TF")
         lib.pe_set_conv_impl(2)
-        lib.pe_set_conv_ablation(0)
-        lib.pe_set_conv_tile256(41)
+        lib.pe_set_conv_tile256(9)
+        if k == 3 and L.conv_wd_supported(3, 1, H, W, Cin, Cout):
+            pk = L.conv_wd_pack(w)
+            ms = timeit(lambda: L.conv3x3_wd(x, pk, b, Cout, relu=True, out=out))
+            row.append(f"weights-direct: {ms:.4f}ms {fl / ms / 1e9:6.0f}TF")
         print(f"N{N} {H}x{W} {Cin}->{Cout} k{k} | " + " | ".join(row), flush=True)
 
 

@@ -72,7 +72,7 @@ def test_conv_matches_torch(L, case):
 @pytest.mark.parametrize("case", [(8, 100, 128, 128, 256, 3, 1, True, 0), (9, 99, 131, 256, 512, 1, 1, True, 1),
                                   (8, 100, 128, 256, 256, 1, 1, False, 2), (16, 51, 64, 512, 256, 1, 2, False, 0),
                                   (8, 100, 128, 64, 256, 1, 1, True, 0), (8, 100, 128, 128, 256, 1, 1, False, 1)])
-@pytest.mark.parametrize("policy", [25, 64, 128])
+@pytest.mark.parametrize("policy", [25])
 def test_conv_big_tile_kernel(L, case, policy):
     """The 256x256 two-stage kernel (tile policy bit 3) against torch, incl. ragged M, residual modes, stride 2."""
     import proben_amd
@@ -94,23 +94,22 @@ def test_conv_big_tile_kernel(L, case, policy):
         res = nhwc(res)
     if relu:
         ref = ref.relu()
-    # 25: 256x256 two-stage kernel everywhere, 64: 256x256 four-stage ring kernel, 128: 256x256 phase-split kernel
+    # 25: 256x256 two-stage kernel everywhere it applies
     lib.pe_set_conv_tile256(policy)
     try:
         out = L.conv2d_nhwc(nhwc(x), w.permute(0, 2, 3, 1).contiguous(), b, kernel=k, stride=s, relu=relu, residual=res, residual_mode=res_mode)
         torch.cuda.synchronize()
     finally:
-        lib.pe_set_conv_tile256(41)
+        lib.pe_set_conv_tile256(9)
     torch.testing.assert_close(out.permute(0, 3, 1, 2).float(), ref, rtol=4e-3, atol=4e-3)
 
 
 @pytest.mark.parametrize("case", [(16, 100, 128, 128, 128, 3, 1, True, 0), (9, 99, 131, 64, 256, 3, 1, False, 0),
-                                  (2, 25, 32, 256, 256, 3, 1, True, 0), (3, 40, 50, 64, 64, 3, 1, True, 0),
-                                  (16, 101, 127, 128, 256, 3, 1, True, 512)])
+                                  (2, 25, 32, 256, 256, 3, 1, True, 0), (3, 40, 50, 64, 64, 3, 1, True, 0)])
 def test_conv3x3_weight_double_buffered_kernel(L, case):
-    """The kw-reuse 3x3 kernel with the double-buffered weight tile (tile policy bit 5), 128- and 256-row tiles."""
+    """The kw-reuse 3x3 kernel with the double-buffered weight tile, 128- and 256-row tiles."""
     import proben_amd
-    N, H, W, Cin, Cout, k, s, relu, rows = case   # rows = 512: the experimental 512-row / 16-wave tile (policy bit 8)
+    N, H, W, Cin, Cout, k, s, relu, rows = case
     lib = proben_amd._lib.lib()
     g = torch.Generator(device="cpu").manual_seed(13)
     x = torch.randn(N, Cin, H, W, generator=g).cuda().half()
@@ -119,35 +118,71 @@ def test_conv3x3_weight_double_buffered_kernel(L, case):
     ref = torch.nn.functional.conv2d(x.float(), w.float(), b, stride=s, padding=1)
     if relu:
         ref = ref.relu()
-    lib.pe_set_conv_tile256(9 | 32 | (256 if rows == 512 else 0))
+    lib.pe_set_conv_tile256(9)
     try:
         out = L.conv2d_nhwc(nhwc(x), w.permute(0, 2, 3, 1).contiguous(), b, kernel=k, stride=s, relu=relu)
         torch.cuda.synchronize()
     finally:
-        lib.pe_set_conv_tile256(41)
+        lib.pe_set_conv_tile256(9)
     torch.testing.assert_close(out.permute(0, 3, 1, 2).float(), ref, rtol=4e-3, atol=4e-3)
 
 
-@pytest.mark.parametrize("case", [(8, 100, 128, 128, 256), (9, 99, 131, 64, 256), (16, 51, 67, 256, 512), (5, 200, 256, 192, 256)])
-def test_conv3x3_phase_split_slab_kernel(L, case):
-    """The experimental 256x256 phase-split kernel with the kw-reuse slab (tile policy bit 10): ragged M, image-row
-    wrap inside a tile, minimal (3 groups) and odd (9 groups) group counts, two N tiles; run twice (race screen)."""
-    import proben_amd
-    N, H, W, Cin, Cout = case
-    lib = proben_amd._lib.lib()
-    g = torch.Generator(device="cpu").manual_seed(17)
+@pytest.mark.parametrize("case", [
+    # N, H, W, Cin, Cout, relu, out window (offset, stride)
+    (3, 50, 64, 256, 256, True, None),      # res4 geometry: two image rows per tile, tiles straddle images
+    (2, 20, 256, 64, 256, False, None),     # p2 geometry: half a row per tile (left / right halo from the neighbour tile)
+    (3, 5, 32, 128, 512, True, None),       # four rows per tile, M = 480 is not a multiple of the 128-pixel tile, two N tiles
+    (2, 13, 128, 256, 256, False, (256, 512)),  # one row per tile; output written into a channel window (middle fusion)
+    (1, 7, 384, 64, 256, True, None),       # W = 3 x 128
+    (4, 25, 32, 512, 512, True, None),      # res5 geometry
+])
+def test_conv3x3_weights_direct_kernel(L, case):
+    """csrc/conv_wd.h (weights streamed L2 -> VGPR in fragment order, pixel slab with explicit halo in LDS) against
+    torch fp32: image borders, tile seams inside and across image rows, ragged M, bias folded into the accumulators,
+    channel-window output.  Run twice (race screen: the LDS ring is published by one barrier per 12 K-steps)."""
+    N, H, W, Cin, Cout, relu, window = case
+    g = torch.Generator(device="cpu").manual_seed(23)
     x = torch.randn(N, Cin, H, W, generator=g).cuda().half()
     w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5).cuda().half()
     b = torch.randn(Cout, generator=g).cuda()
-    ref = torch.nn.functional.conv2d(x.float(), w.float(), b, stride=1, padding=1).relu()
-    lib.pe_set_conv_tile256(41 | 1024)
-    try:
-        outs = [L.conv2d_nhwc(nhwc(x), w.permute(0, 2, 3, 1).contiguous(), b, kernel=3, relu=True) for _ in range(2)]
-        torch.cuda.synchronize()
-    finally:
-        lib.pe_set_conv_tile256(41)
+    ref = torch.nn.functional.conv2d(x.float(), w.float(), b, stride=1, padding=1)
+    if relu:
+        ref = ref.relu()
+    assert L.conv_wd_supported(3, 1, H, W, Cin, Cout)
+    packed = L.conv_wd_pack(w.permute(0, 2, 3, 1).contiguous())
+    outs = []
+    for _ in range(2):
+        if window is None:
+            o = L.conv3x3_wd(nhwc(x), packed, b, Cout, relu=relu)
+        else:
+            off, stride = window
+            full = torch.full((N, H, W, stride), 7.0, dtype=torch.float16, device="cuda")
+            L.conv3x3_wd(nhwc(x), packed, b, Cout, relu=relu, out=full.view(-1)[off:], out_stride=stride)
+            assert torch.all(full[..., :off] == 7.0)          # the other half of the window is untouched
+            o = full[..., off:off + Cout]
+        outs.append(o.clone())
+    torch.cuda.synchronize()
     assert torch.equal(outs[0], outs[1])
     torch.testing.assert_close(outs[0].permute(0, 3, 1, 2).float(), ref, rtol=4e-3, atol=4e-3)
+
+
+def test_conv3x3_weights_direct_matches_lds_kernel_and_rejects_other_geometry(L):
+    """Same fp16 inputs through the weights-direct and the LDS-DMA 3x3 kernels: both accumulate in fp32 over the same
+    products, so they agree to fp32 summation-order noise; unsupported widths are refused loudly."""
+    import proben_amd
+    g = torch.Generator(device="cpu").manual_seed(29)
+    x = torch.randn(2, 50, 64, 256, generator=g).cuda().half().relu()
+    w = (torch.randn(256, 3, 3, 256, generator=g) / 48.0).cuda().half()
+    b = torch.randn(256, generator=g).cuda()
+    a = L.conv3x3_wd(x, L.conv_wd_pack(w), b, 256, relu=True).float()
+    c = L.conv2d_nhwc(x, w, b, kernel=3, relu=True).float()
+    torch.testing.assert_close(a, c, rtol=2e-3, atol=2e-3)
+    assert not L.conv_wd_supported(3, 1, 40, 52, 256, 256)      # W % 32 != 0
+    assert not L.conv_wd_supported(3, 1, 40, 64, 256, 128)      # Cout % 256 != 0
+    assert not L.conv_wd_supported(1, 1, 40, 64, 256, 256)
+    xx = torch.zeros(1, 8, 52, 256, device="cuda", dtype=torch.float16)
+    with pytest.raises(proben_amd._lib.HipLibraryError):
+        L.conv3x3_wd(xx, L.conv_wd_pack(w), b, 256)
 
 
 def test_conv_transpose_detecting(L):
