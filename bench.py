@@ -1,81 +1,160 @@
 """Headline benchmark: RGB+T frame-pairs / second on 640x512 FLIR-shaped frames.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--depth 101]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 1|2|3|4] [--batch B] [--feed hbm|host]
 
-Workload (BASELINE.json configs[2]): two Faster R-CNN R101-FPN detectors (thermal + RGB, K = 3, fp16 MFMA
-convs / fp32 post-ops) + ProbEn fusion (probEn score, v-avg box), batch 32 frame pairs per GPU, synthetic
-uint8 frames resident in HBM, random-init weights of the real architecture.  One step = one batch through
-resize -> normalise/pad -> both detectors -> ProbEn (-> RCCL all-gather of the fused rows when N > 1).
-Images shard across ranks with no data-path collective ("weak" scaling: per-GPU batch fixed).
+Default workload (BASELINE.json configs[2]): two Faster R-CNN R101-FPN detectors (thermal + RGB, K = 3, fp16 MFMA
+convs / fp32 post-ops) + ProbEn fusion (probEn score, v-avg box), batch 32 frame pairs per GPU, synthetic uint8
+frames, random-init weights of the real architecture.  One step = one batch through resize -> normalise/pad ->
+every detector -> ProbEn (-> RCCL all-gather of the fused rows when N > 1).  Images shard across ranks with no
+data-path collective ("weak" scaling: per-GPU batch fixed).
+  --config 1: configs[1] thermal-only R101-FPN, batch 16           (metric unit: frames/s)
+  --config 3: configs[3] thermal (3-ch) + early (4-ch) + middle (6-ch, two backbone passes, 512-ch heads) + 3-way ProbEn
+  --config 4: configs[4] KAIST: two R50-FPN detectors, K = 1, binary ProbEn
+  --feed hbm (default): the frames are resident in HBM before the timed region (the metric's definition);
+  --feed host: frames start in pinned host memory and a double-buffered uploader moves every batch over PCIe INSIDE
+               the timed loop (reported as such; never the headline value).
 
-Prints ONE JSON line on rank 0 with the throughput, the roofline of the dominant kernel (HIP events around
-every launch of it in one extra instrumented step) and the CPU baseline (the oracle's restatement of the
-reference's MODEL.DEVICE=cpu path timed on the host cores, bounded sample).
+Multi-GPU: `python bench.py --gpus N` launches N ranks itself (torch.distributed.run, one process per GPU, backend
+nccl = RCCL) when it is not already running under a launcher; `n_gpus` in the line is the world size RCCL reports.
+
+Prints ONE JSON line on rank 0 with the throughput, the roofline of the dominant kernel (HIP events around every
+distinct launch replayed back-to-back), the ProbEn kernel's B = 4096 micro-figure and the CPU baseline (the oracle's
+restatement of the reference's MODEL.DEVICE=cpu path timed on the host cores, all cores and 1 thread, bounded sample).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
 MFMA_F16_DENSE_PEAK_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense bf16/fp16
 HBM_PEAK_GBS = 8000.0                # same guide: HBM3E 8.0 TB/s spec (~6.3 TB/s achievable)
-GFLOP_PER_PAIR = 897.4               # 2 x 448.7 GFLOP (R101-FPN, 800x1024, R = 1000, K = 3)
+
+# workloads: detectors = input channels per detector; GFLOP per unit from SURVEY 8(d)
+CONFIGS = {
+    1: dict(title="configs[1]: FLIR thermal-only R101-FPN inference", detectors=(3,), depth=101, K=3, batch=16,
+            fuse=None, unit="frames/s", gflop=448.7),
+    2: dict(title="configs[2]: FLIR RGB + thermal two-detector ProbEn (probEn/v-avg)", detectors=(3, 3), depth=101, K=3,
+            batch=32, fuse=("probEn", "v-avg"), unit="frame-pairs/s", gflop=897.4),
+    3: dict(title="configs[3]: FLIR thermal + early (4-ch) + middle (6-ch) three-model ProbEn (probEn/v-avg)",
+            detectors=(3, 4, 6), depth=101, K=3, batch=32, fuse=("probEn", "v-avg"), unit="frame-pairs/s", gflop=None),
+    4: dict(title="configs[4]: KAIST RGB + thermal ProbEn (binary probEn/v-avg), R50-FPN x2, K=1", detectors=(3, 3), depth=50,
+            K=1, batch=32, fuse=("probEn_binary", "v-avg"), unit="frame-pairs/s", gflop=None),
+}
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=32, help="frame pairs per GPU per step")
-    ap.add_argument("--depth", type=int, default=101)
+    ap.add_argument("--steps", type=int, default=250, help="timed steps (default 250 = ~10 s of device work at ~40 ms / step)")
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
+    ap.add_argument("--batch", type=int, default=0, help="frame pairs per GPU per step (0 = the config's own)")
+    ap.add_argument("--depth", type=int, default=0, help="override the backbone depth (50 | 101)")
+    ap.add_argument("--feed", choices=("hbm", "host"), default="hbm")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-micro", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=8)
     ap.add_argument("--cpu-threads", type=int, default=16)
-    ap.add_argument("--conv-impl", type=int, default=2, help="1: register-staged conv kernel, 2: LDS-DMA conv kernel")
-    ap.add_argument("--serial-detectors", action="store_true", help="run the two detectors back to back on one stream")
+    ap.add_argument("--conv-impl", type=int, default=2, help="1: register-staged conv kernel, 2: LDS-DMA conv kernels")
+    ap.add_argument("--no-wd", action="store_true", help="A/B: do not use the weights-direct 3x3 kernel")
+    ap.add_argument("--serial-detectors", action="store_true", help="run the detectors back to back on one stream")
     ap.add_argument("--stagger", type=int, default=3,
-                    help="N > 0 (default 3): throughput mode of the pipeline - detector 2 trails detector 1 by its res<N> stage and "
-                         "batches follow each other without a device-wide wait (all K timed steps still complete inside the "
-                         "timed region); 0: every step waits for its own fusion before the next one starts")
+                    help="N > 0 (default 3, two-detector configs): throughput mode of the pipeline - detector 2 trails detector 1 by its "
+                         "res<N> stage and batches follow each other without a device-wide wait (all K timed steps still complete "
+                         "inside the timed region); 0: every step waits for its own fusion before the next one starts")
     ap.add_argument("--tile256", type=int, default=-1, help="conv tile policy override (pe_set_conv_tile256)")
     ap.add_argument("--layers", type=str, default="", help="write a per-conv-launch table (shape, ms, TFLOP/s) to this file")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
-def build_models(depth, device):
+# ----------------------------------------------------------------------------------------------------------------
+# multi-rank launch (replaces the reference's detectron2/engine/launch.py:24-84 mp.spawn + init_process_group)
+# ----------------------------------------------------------------------------------------------------------------
+def launch_command(argv, nproc, port, script=None):
+    """The command `bench.py --gpus N` re-executes itself with when it is not already under a launcher."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), script or os.path.abspath(__file__)] + list(argv)
+
+
+def free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def maybe_self_launch(args, argv):
+    """--gpus N > 1 without RANK / WORLD_SIZE in the environment: spawn the N ranks and exit with their status."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    import torch
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} requested but only {have} GPU(s) are visible; refusing to report a "
+                 f"{args.gpus}-GPU line from fewer devices")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL / cross-process tensor sharing on this driver)
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    sys.exit(subprocess.call(launch_command(argv, args.gpus, free_port()), env=env))
+
+
+# ----------------------------------------------------------------------------------------------------------------
+def build_models(cfg, depth, device, use_wd=True):
     import proben_amd  # noqa: F401
     from proben_amd.rcnn import DetectorConfig, GeneralizedRCNN
     from proben_amd.synthetic import synthetic_state_dict
-    sds = [synthetic_state_dict(depth, 3, 3, seed=s) for s in (1, 2)]  # thermal, RGB
-    models = [GeneralizedRCNN(DetectorConfig(), sd, device) for sd in sds]
+    fmt = {3: "BGR", 4: "BGRT", 6: "BGRTTT"}
+    models, sds = [], []
+    for i, ch in enumerate(cfg["detectors"]):
+        sd = synthetic_state_dict(depth, cfg["K"], ch, seed=i + 1)
+        mean = (103.53, 116.28, 123.675) + (135.438,) * (ch - 3)
+        m = GeneralizedRCNN(DetectorConfig(num_classes=cfg["K"], input_format=fmt[ch], pixel_mean=mean, pixel_std=(1.0,) * ch), sd, device)
+        m.use_wd = use_wd
+        models.append(m)
+        sds.append(sd)
     return models, sds
 
 
-def make_step(models, frames_t, frames_rgb, world, rank, with_comm=True, concurrent=True, stagger=0):
+def make_frames(cfg, B, rank, device=None, pinned=False):
+    """One uint8 [B,512,640,C] batch per detector (synthetic FLIR-shaped frames)."""
+    import torch
+    from proben_amd.synthetic import synthetic_images
+    out = []
+    for i, ch in enumerate(cfg["detectors"]):
+        t = torch.from_numpy(synthetic_images(B, channels=ch, seed=10 + 990 * i + rank))
+        out.append(t.pin_memory() if pinned else t.to(device))
+    return out
+
+
+def make_step(models, frames, cfg, world, with_comm=True, concurrent=True, stagger=0, feeder=None):
+    import torch
     from proben_amd.pipeline import FramePairPipeline
-    B = frames_t.shape[0]
+    B = frames[0].shape[0]
     out_sizes = [(512, 640)] * B
-    pipe = FramePairPipeline(models, "probEn", "v-avg", concurrent=concurrent, staggered=stagger > 0, stagger_stage=stagger or 4)
+    fuse = cfg["fuse"] or ("probEn", "v-avg")
+    pipe = FramePairPipeline(models, fuse[0], fuse[1], concurrent=concurrent, staggered=stagger > 0 and len(models) == 2,
+                             stagger_stage=stagger or 4, fuse=cfg["fuse"] is not None)
 
     def step():
-        (det_t, det_r), fused = pipe([frames_t, frames_rgb], out_sizes, (800, 1000))  # [B,512,640,3] uint8 batches
+        batch = feeder.next() if feeder is not None else frames
+        dets, fused = pipe(batch, out_sizes, (800, 1000))
+        if feeder is not None:
+            feeder.mark_consumed(*(pipe.streams or []))
         if world > 1 and with_comm:
             from proben_amd import comm
+            payload = fused if fused is not None else {k: dets[0][k] for k in ("boxes", "scores", "classes", "counts")}
             if pipe.staggered:   # the fused rows live on the second detector's stream
                 with torch.cuda.stream(pipe.streams[1]):
-                    comm.all_gather_fused_rows(fused)
+                    comm.all_gather_fused_rows(payload)
             else:
-                comm.all_gather_fused_rows(fused)
-        return det_t, det_r, fused
+                comm.all_gather_fused_rows(payload)
+        return dets, fused
     step.pipe = pipe
     return step
 
@@ -86,6 +165,7 @@ def roofline_leg(step, layers_path="", reps=10):
     replayed `reps` times back-to-back between two events on the launch stream (GPU-bound, no host gaps).
     Per-variant time of one step = sum over its launches of that configuration's average duration -
     the same quantity `rocprofv3 --kernel-trace --stats` reports as AverageNs x Calls."""
+    import torch
     from proben_amd import layers as L
     L.PROFILE = []
     step()
@@ -97,7 +177,6 @@ def roofline_leg(step, layers_path="", reps=10):
     timing = {}
     for key, r in distinct.items():
         replay = r["replay"]
-        L.PROFILE = None
         for _ in range(2):
             replay()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -127,31 +206,31 @@ def roofline_leg(step, layers_path="", reps=10):
         tf, gbs = fl / t / 1e12, by / t / 1e9
         # machine balance 2500 TFLOP/s / 8000 GB/s = 312 flop/byte decides which roof bounds the kernel
         hbm_bound = fl / by < MFMA_F16_DENSE_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBS
-        d = {"bound": "hbm" if hbm_bound else "mfma", "kernel": name,
-             "achieved": round(gbs if hbm_bound else tf, 1), "peak": HBM_PEAK_GBS if hbm_bound else MFMA_F16_DENSE_PEAK_TFLOPS,
-             "unit": "GB/s" if hbm_bound else "TFLOP/s",
-             "frac": round((gbs / HBM_PEAK_GBS) if hbm_bound else (tf / MFMA_F16_DENSE_PEAK_TFLOPS), 4), "traffic": None,
-             "launches_per_step": n, "avg_launch_ms": round(t / n * 1e3, 4), "gflop_per_launch": round(fl / n / 1e9, 2),
-             "algorithmic_mbytes_per_launch": round(by / n / 1e6, 1), "flop_per_byte": round(fl / by, 1),
-             "tflops": round(tf, 1), "algorithmic_gbs": round(gbs, 1)}
-        return d
+        return {"bound": "hbm" if hbm_bound else "mfma", "kernel": name,
+                "achieved": round(gbs if hbm_bound else tf, 1), "peak": HBM_PEAK_GBS if hbm_bound else MFMA_F16_DENSE_PEAK_TFLOPS,
+                "unit": "GB/s" if hbm_bound else "TFLOP/s",
+                "frac": round((gbs / HBM_PEAK_GBS) if hbm_bound else (tf / MFMA_F16_DENSE_PEAK_TFLOPS), 4), "traffic": None,
+                "launches_per_step": n, "avg_launch_ms": round(t / n * 1e3, 4), "gflop_per_launch": round(fl / n / 1e9, 2),
+                "algorithmic_mbytes_per_launch": round(by / n / 1e6, 1), "flop_per_byte": round(fl / by, 1),
+                "tflops": round(tf, 1), "algorithmic_gbs": round(gbs, 1)}
     # HBM traffic per launch from the PMC counters: measured by separate `rocprofv3 --pmc` passes (they cannot run
     # inside this process); profiles/*_pmc_traffic.json holds the last committed measurement per kernel name
-    traffic = {}
+    traffic, traffic_src = {}, ""
     try:
         import glob
         for pth in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json"))):
-            traffic = json.load(open(pth))["kernels"]
+            for k, v in json.load(open(pth))["kernels"].items():
+                traffic[k.replace(" ", "")] = (v, os.path.basename(pth))
     except Exception:
         traffic = {}
 
     def with_traffic(d):
-        key = d["kernel"].replace(" ", "")
-        for k, v in traffic.items():
-            if k.replace(" ", "") == key:
-                d["traffic"] = round(v["hbm_mb_per_launch"] * 1e6)   # HBM bytes per launch (compare: algorithmic_mbytes_per_launch)
-                d["traffic_detail"] = {"hbm_mbytes_per_launch": v["hbm_mb_per_launch"], "unit": "MB",
-                                       "source": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE, separate passes, profiles/r01_pmc_traffic.json"}
+        hit = traffic.get(d["kernel"].replace(" ", ""))
+        if hit:
+            v, src = hit
+            d["traffic"] = round(v["hbm_mb_per_launch"] * 1e6)   # HBM bytes per launch (compare: algorithmic_mbytes_per_launch)
+            d["traffic_detail"] = {"hbm_mbytes_per_launch": v["hbm_mb_per_launch"], "unit": "MB",
+                                   "source": f"rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE, separate passes, profiles/{src}"}
         return d
     dom = max(agg, key=lambda k: agg[k][2])
     out = with_traffic(describe(dom))
@@ -160,68 +239,113 @@ def roofline_leg(step, layers_path="", reps=10):
     if k3 is not None and k3 != dom:
         out["conv3x3"] = with_traffic(describe(k3))
     out["method"] = ("avg_launch_ms = HIP-event timing of every distinct launch replayed back-to-back on the launch stream; "
-                     "agrees with rocprofv3 --kernel-trace --stats of `bench.py --serial-detectors` "
-                     "(profiles/r01_final_kernel_stats.csv).  In the default two-stream run co-running kernels stretch each "
-                     "other's durations 1.5-1.8x (profiles/r01_final_kernel_stats_two_streams.csv) while the step gets shorter.")
+                     "agrees with rocprofv3 --kernel-trace --stats of `bench.py --serial-detectors` (profiles/).  In the default "
+                     "two-stream run co-running kernels stretch each other's durations while the step gets shorter.")
     out["all_conv_variants"] = {k: {"launches": v[0], "gflop": round(v[1] / 1e9, 1), "ms": round(v[2] * 1e3, 3),
                                     "tflops": round(v[1] / v[2] / 1e12, 1), "algorithmic_gbs": round(v[3] / v[2] / 1e9, 0)}
                                 for k, v in sorted(agg.items(), key=lambda kv: -kv[1][2])}
     return out
 
 
-def cpu_baseline(sds, depth, pairs, threads):
+def proben_micro(device, B=4096, reps=20):
+    """SURVEY 8(d) config-3 micro-benchmark of the fused ProbEn kernel: B = 4096 images, n1, n2 ~ U{0..100}, 30 % cross-detector
+    near-duplicates, K = 3, seed 2; algorithmic bytes = N*(4+1+K+1)*8 + N*4 in, M*(4+1+1)*4 out."""
+    import numpy as np
+    import torch
+    from proben_amd import fusion as F
+    from proben_amd.synthetic import synth_detections
+    per_image = synth_detections(B, seed=2, kdet=2, nmax=100, K=3)
+    b, s, p, v, c, offs = F.pack_infos(per_image, device)
+    nmax = int((offs[1:] - offs[:-1]).max().item())
+    out = F.fuse_batch(b, s, p, v, c, offs, "probEn", "v-avg", max_rows=nmax)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        out = F.fuse_batch(b, s, p, v, c, offs, "probEn", "v-avg", max_rows=nmax)
+    e1.record()
+    torch.cuda.synchronize()
+    sec = e0.elapsed_time(e1) / reps * 1e-3
+    n_in, n_out = int(b.shape[0]), int(out["counts"].clamp(min=0).sum().item())
+    nbytes = n_in * ((4 + 1 + 3 + 1) * 8 + 4) + n_out * (4 + 1 + 1) * 4
+    return {"images": B, "rows_in_mean": round(n_in / B, 1), "rows_out_mean": round(n_out / B, 1), "ms_per_launch": round(sec * 1e3, 4),
+            "us_per_image": round(sec / B * 1e6, 4), "images_per_s": round(B / sec), "algorithmic_gbs": round(nbytes / sec / 1e9, 2),
+            "note": "one wavefront per image, float64; latency / LDS bound, not HBM bound (the whole batch is " + str(round(nbytes / 1e6, 1)) + " MB)"}
+
+
+def cpu_baseline(sds, cfg, depth, pairs, threads):
     """The oracle = this repo's restatement of the reference's CPU path (torch fp32 NCHW unfused conv/BN/ReLU,
-    all-anchor decode, per-level sort, per-level ROIAlign, NumPy-f64 ProbEn), timed on the host cores."""
+    all-anchor decode, per-level sort, per-level ROIAlign, NumPy-f64 ProbEn), timed on the host cores: all `threads`
+    on `pairs` units, then ONE thread on one unit (SURVEY 8d asks for both)."""
+    import torch
     from oracle import detector as D
     from oracle import proben as O
     from proben_amd.synthetic import synthetic_images
+    chans = cfg["detectors"]
+    specs = [D.DetectorSpec(depth=depth, in_channels=ch, num_classes=cfg["K"]) for ch in chans]
+
+    def run(n_units, nthreads):
+        torch.set_num_threads(nthreads)
+        imgs = [synthetic_images(n_units, channels=ch, seed=100 * (i + 1)) for i, ch in enumerate(chans)]
+        t0 = time.time()
+        for u in range(n_units):
+            dets = []
+            for sd, spec, im in zip(sds, specs, imgs):
+                x = torch.from_numpy(im[u]).permute(2, 0, 1).float()[None]
+                x = torch.nn.functional.interpolate(x, size=(800, 1000), mode="bilinear", align_corners=False)[0]
+                o = D.forward([x], sd, spec, out_sizes=[(512, 640)])[0]
+                keep = o["classes"] <= 2
+                dets.append({"bbox": o["boxes"][keep].double().numpy(), "score": o["scores"][keep].double().numpy(),
+                             "class": o["classes"][keep].numpy(), "prob": o["prob_score"][keep].double().numpy(),
+                             "vars": o["vars"][keep].double().numpy()})
+            live = [d for d in dets if len(d["score"])]
+            if cfg["fuse"] is not None and len(live) >= 2:
+                O.nms_bayesian(*O.concat_infos(live), 0.5, cfg["fuse"][0].replace("probEn_binary", "probEn_binary"), cfg["fuse"][1])
+        return time.time() - t0
     threads = max(1, min(threads, os.cpu_count() or 1))  # torch CPU convs degrade badly when oversubscribed
-    torch.set_num_threads(threads)
-    spec = D.DetectorSpec(depth=depth)
-    imgs_t = synthetic_images(pairs, seed=100)
-    imgs_r = synthetic_images(pairs, seed=200)
-    t0 = time.time()
-    for i in range(pairs):
-        dets = []
-        for sd, im in ((sds[0], imgs_t[i]), (sds[1], imgs_r[i])):
-            x = torch.from_numpy(im).permute(2, 0, 1).float()[None]
-            x = torch.nn.functional.interpolate(x, size=(800, 1000), mode="bilinear", align_corners=False)[0]
-            o = D.forward([x], sd, spec, out_sizes=[(512, 640)])[0]
-            keep = o["classes"] <= 2
-            dets.append({"bbox": o["boxes"][keep].double().numpy(), "score": o["scores"][keep].double().numpy(),
-                         "class": o["classes"][keep].numpy(), "prob": o["prob_score"][keep].double().numpy(),
-                         "vars": o["vars"][keep].double().numpy()})
-        live = [d for d in dets if len(d["score"])]
-        if len(live) >= 2:
-            O.nms_bayesian(*O.concat_infos(live), 0.5, "probEn", "v-avg")
-    dt = time.time() - t0
-    return {"value": round(pairs / dt, 4), "unit": "frame-pairs/s", "cores": threads, "kind": "port",
-            "sample": f"{pairs} frame pair(s): 2 x R{depth}-FPN oracle forward (torch {torch.__version__} CPU fp32, "
-                      f"{threads} threads) + NumPy-f64 ProbEn, {dt:.1f} s"}
+    dt = run(pairs, threads)
+    dt1 = run(1, 1)
+    what = f"{len(chans)} x R{depth}-FPN oracle forward (torch {torch.__version__} CPU fp32) + NumPy-f64 ProbEn"
+    return {"value": round(pairs / dt, 4), "unit": cfg["unit"], "cores": threads, "kind": "port",
+            "sample": f"{pairs} unit(s): {what}, {threads} threads, {dt:.1f} s",
+            "single_thread": {"value": round(1 / dt1, 4), "unit": cfg["unit"], "cores": 1, "sample": f"1 unit, 1 thread, {dt1:.1f} s"}}
 
 
-def main():
-    args = parse()
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse(argv)
+    maybe_self_launch(args, argv)
+    import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus or world == 1, f"WORLD_SIZE {world} != --gpus {args.gpus}"
+    if world != args.gpus:
+        sys.exit(f"bench.py: WORLD_SIZE {world} != --gpus {args.gpus}")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
-    from proben_amd.synthetic import synthetic_images
-    models, sds = build_models(args.depth, dev)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        world = dist.get_world_size()   # the line reports what RCCL saw
+    cfg = CONFIGS[args.config]
+    depth = args.depth or cfg["depth"]
+    B = args.batch or cfg["batch"]
+    models, sds = build_models(cfg, depth, dev, use_wd=not args.no_wd)
     from proben_amd import _lib
     _lib.check(_lib.lib().pe_set_conv_impl(args.conv_impl), "pe_set_conv_impl")
     if args.tile256 >= 0:
         _lib.lib().pe_set_conv_tile256(args.tile256)
-    B = args.batch
-    frames_t = torch.from_numpy(synthetic_images(B, seed=10 + rank)).to(dev)
-    frames_rgb = torch.from_numpy(synthetic_images(B, seed=1000 + rank)).to(dev)
-    step = make_step(models, frames_t, frames_rgb, world, rank, concurrent=not args.serial_detectors, stagger=args.stagger)
+    feeder = None
+    if args.feed == "host":
+        from proben_amd.pipeline import HostFeeder
+        frames = make_frames(cfg, B, rank, pinned=True)
+        feeder = HostFeeder(frames, dev)
+        frames_dev = [f.to(dev) for f in frames]
+    else:
+        frames = frames_dev = make_frames(cfg, B, rank, dev)
+    stagger = args.stagger if len(models) == 2 and not args.serial_detectors else 0
+    step = make_step(models, frames_dev, cfg, world, concurrent=not args.serial_detectors, stagger=stagger, feeder=feeder)
 
     def fence():
         if world > 1:
@@ -240,30 +364,38 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
-    det_t, det_r, fused = out
-    n_det = float(det_t["counts"].float().mean() + det_r["counts"].float().mean()) / 2
-    n_fused = float(fused["counts"].float().mean())
+    dets, fused = out
+    n_det = float(sum(d["counts"].float().mean() for d in dets)) / len(dets)
     if rank == 0:
-        pairs = world * B * args.steps
-        value = pairs / dt
+        units = world * B * args.steps
+        value = units / dt
+        sched = ("one stream" if args.serial_detectors else
+                 ("two detector streams, staggered by res%d, batches back to back" % stagger) if stagger > 0 else
+                 "%d detector stream(s), step by step" % len(models))
         line = {
-            "metric": "RGB+T frame-pairs/sec (FLIR-aligned 640x512, two R101-FPN detectors + ProbEn)",
-            "value": round(value, 2), "unit": "frame-pairs/s", "n_gpus": world, "steps": args.steps,
+            "metric": ("RGB+T frame-pairs/sec (FLIR-aligned 640x512, two R101-FPN detectors + ProbEn)" if args.config == 2 else
+                       "frames or frame-pairs/sec, 640x512, " + cfg["title"]),
+            "value": round(value, 2), "unit": cfg["unit"], "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": f"configs[2]: FLIR RGB + thermal two-detector ProbEn (probEn/v-avg), batch {B} pairs per GPU, "
-                                   f"R{args.depth}-FPN x2, 640x512 -> 800x1000 (padded 800x1024), K=3, random-init weights",
-                       "batch_pairs_per_gpu": B, "detections_per_image_mean": round(n_det, 1),
-                       "fused_rows_per_pair_mean": round(n_fused, 1),
-                       "end_to_end_tflops": round(value * GFLOP_PER_PAIR / 1e3, 1),
-                       "schedule": ("two detector streams, staggered by res%d, batches back to back" % args.stagger) if args.stagger > 0
-                                   and not args.serial_detectors else ("one stream" if args.serial_detectors else "two detector streams, step by step")},
+            "config": {"workload": f"{cfg['title']}, batch {B} per GPU, R{depth}-FPN x{len(models)}, 640x512 -> 800x1000 (padded 800x1024), "
+                                   f"K={cfg['K']}, random-init weights",
+                       "batch_per_gpu": B, "detections_per_image_mean": round(n_det, 1),
+                       "fused_rows_per_pair_mean": round(float(fused["counts"].float().mean()), 1) if fused is not None else None,
+                       "end_to_end_tflops": round(value * cfg["gflop"] / 1e3, 1) if cfg["gflop"] else None,
+                       "input_residency": ("frames resident in HBM before the timed region (no H2D inside it)" if feeder is None else
+                                           "frames in pinned host memory; double-buffered H2D upload of every batch INSIDE the timed region"),
+                       "timed_seconds": round(dt, 2), "schedule": sched},
         }
+        if world > 1:
+            line["config"]["collective"] = "one all_gather_into_tensor of the fused rows per step (RCCL)"
         if not args.no_roofline:
             # rank-local leg: no collective inside (the other ranks are already waiting at the final barrier)
-            line["roofline"] = roofline_leg(make_step(models, frames_t, frames_rgb, world, rank, with_comm=False, concurrent=False), args.layers)
+            line["roofline"] = roofline_leg(make_step(models, frames_dev, cfg, world, with_comm=False, concurrent=False), args.layers)
+        if not args.no_micro:
+            line["proben_micro"] = proben_micro(dev)
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(sds, args.depth, args.cpu_pairs, args.cpu_threads)
+            line["cpu_baseline"] = cpu_baseline(sds, cfg, depth, args.cpu_pairs, args.cpu_threads)
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.barrier()

@@ -154,8 +154,11 @@ def fuse_detections(dets, score_fusion="probEn", box_fusion="v-avg", max_class=2
         single = osingle.bool()
         keep = torch.where(single[:, None], torch.arange(S, dtype=torch.int32, device=dev).expand(B, S), keep)
         kcnt = torch.where(single, ocnt, kcnt)
-        return {"keep": keep, "counts": kcnt, "boxes": ob, "scores": os_.float(), "classes": oc.float(),
-                "offsets": ooff, "stride": S, "nms_route": True}
+        # same contract as the ProbEn route: image b's fused rows are [offsets[b], offsets[b] + counts[b]) of the flat
+        # arrays (score-descending), so late_fusion.fused_rows_device / comm.all_gather_fused_rows need no special case
+        g = (torch.arange(B, device=dev).view(B, 1) * S + keep.clamp(0, S - 1).long()).view(-1)
+        return {"boxes": ob[g], "scores": os_.float()[g], "classes": oc.float()[g], "counts": kcnt, "keep": keep,
+                "offsets": ooff, "stride": S, "in_counts": ocnt, "nms_route": True}
     out = fuse_batch(ob, os_, op, ov, oc, ooff, score_fusion, box_fusion, max_rows=S, iou_thresh=iou_thresh,
                      row_counts=ocnt, passthrough=osingle)
     out["offsets"], out["stride"], out["in_counts"] = ooff, S, ocnt

@@ -270,7 +270,9 @@ def _pil_tables(in_size, out_size, device):
     key = (in_size, out_size, str(device))
     if key not in _PIL_TABLES:
         from .data import pil_bilinear_tables
-        _PIL_TABLES[key] = torch.from_numpy(pil_bilinear_tables(in_size, out_size)).to(device)
+        t = torch.from_numpy(pil_bilinear_tables(in_size, out_size)).to(device)
+        torch.cuda.current_stream(t.device).synchronize()   # the cache is shared by every stream: publish a COMPLETE table
+        _PIL_TABLES[key] = t
     return _PIL_TABLES[key]
 
 

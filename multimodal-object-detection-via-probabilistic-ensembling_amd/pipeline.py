@@ -21,8 +21,9 @@ class FramePairPipeline:
     synchronisation); inputs must not be modified before that either."""
 
     def __init__(self, models, score_fusion="probEn", box_fusion="v-avg", max_class=2, concurrent=True,
-                 staggered=False, stagger_stage=4):
+                 staggered=False, stagger_stage=4, fuse=True):
         self.models = list(models)
+        self.fuse = fuse and len(self.models) > 1   # a single detector has nothing to fuse (configs[1])
         self.method = (score_fusion, box_fusion)
         self.max_class = max_class
         self.concurrent = concurrent and len(self.models) > 1
@@ -30,12 +31,28 @@ class FramePairPipeline:
         self.stagger_stage = stagger_stage
         self.streams = [torch.cuda.Stream() for _ in self.models] if self.concurrent else None
 
-    def wait(self):
-        """Make the current stream wait for everything the pipeline has enqueued (staggered mode)."""
+    def wait(self, results=None):
+        """Make the current stream wait for everything the pipeline has enqueued (staggered mode).  Pass the
+        (dets, fused) a call returned to also tell the caching allocator that those tensors - allocated on the side
+        streams - are now used on the current stream."""
         if self.streams:
             main = torch.cuda.current_stream()
             for st in self.streams:
                 main.wait_stream(st)
+            if results is not None:
+                dets, fused = results
+                for d in list(dets) + ([fused] if fused is not None else []):
+                    for v in d.values():
+                        if isinstance(v, torch.Tensor) and v.is_cuda:
+                            v.record_stream(main)
+
+    @staticmethod
+    def _record(frames, stream):
+        """Inputs are allocated on the caller's stream and read on a side stream: without record_stream the caching
+        allocator may hand their memory to the next batch while the side stream is still reading it."""
+        for f in (frames if isinstance(frames, (list, tuple)) else [frames]):
+            if isinstance(f, torch.Tensor) and f.is_cuda:
+                f.record_stream(stream)
 
     @torch.no_grad()
     def _call_staggered(self, frames_per_detector, out_sizes, resize_to):
@@ -46,6 +63,8 @@ class FramePairPipeline:
         ev_in.record(main)              # inputs are ready; NOT a wait for earlier pipeline work (that lives on sa / sb)
         ev_mid, ev_a = torch.cuda.Event(), torch.cuda.Event()
         sa.wait_event(ev_in)
+        self._record(frames_per_detector[0], sa)
+        self._record(frames_per_detector[1], sb)
         with torch.cuda.stream(sa):
             ma.stage_hook = lambda stage: ev_mid.record(sa) if stage == self.stagger_stage else None
             try:
@@ -78,9 +97,64 @@ class FramePairPipeline:
             dets = []
             for m, fr, st in zip(self.models, frames_per_detector, self.streams):
                 st.wait_stream(main)
+                self._record(fr, st)
                 with torch.cuda.stream(st):
                     dets.append(m.forward_batch(fr, out_sizes=out_sizes, resize_to=resize_to))
             for st in self.streams:
                 main.wait_stream(st)
-        fused = F.fuse_detections(dets, self.method[0], self.method[1], max_class=self.max_class)
+            for d in dets:               # allocated on a side stream, consumed on the main stream from here on
+                for v in d.values():
+                    if isinstance(v, torch.Tensor):
+                        v.record_stream(main)
+        fused = F.fuse_detections(dets, self.method[0], self.method[1], max_class=self.max_class) if self.fuse else None
         return dets, fused
+
+
+class HostFeeder:
+    """Pinned-memory, double-buffered uploader: batches live in page-locked host memory, every `next()`
+    enqueues the H2D copies of one batch on a copy stream into one of two device buffer sets and makes the current
+    stream wait for them; the set being overwritten was consumed two calls ago (an event recorded at the following
+    `next()` proves it), so the upload of batch i+1 overlaps the detectors working on batch i.
+    `host_batches`: list (detectors) of pinned uint8 [B,H,W,C] tensors (one fixed batch, re-uploaded every step) or a
+    callable returning such a list per step."""
+
+    def __init__(self, host_batches, device):
+        self.source = host_batches if callable(host_batches) else (lambda: host_batches)
+        self.device = torch.device(device)
+        self.copy_stream = torch.cuda.Stream(device=self.device)
+        self.bufs = None           # two device buffer sets, allocated from the first batch's shapes
+        self.free = [[], []]   # events after which buffer set k may be overwritten
+        self.k = 0
+        self._last = None
+
+    def next(self):
+        """Upload the next batch; returns the list of device tensors (valid on the current stream)."""
+        cur = torch.cuda.current_stream(self.device)
+        k = self.k
+        self.k ^= 1
+        for ev in self.free[k]:          # set k was handed out two calls ago: wait until its consumers are done
+            self.copy_stream.wait_event(ev)
+        host = self.source()
+        if self.bufs is None:
+            self.bufs = [[torch.empty(t.shape, dtype=t.dtype, device=self.device) for t in host] for _ in range(2)]
+        with torch.cuda.stream(self.copy_stream):
+            for dst, src in zip(self.bufs[k], host):
+                assert src.is_pinned(), "HostFeeder needs page-locked host tensors (tensor.pin_memory())"
+                dst.copy_(src, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(self.copy_stream)
+        cur.wait_event(done)
+        self._last = k
+        return self.bufs[k]
+
+    def mark_consumed(self, *streams):
+        """Call right after enqueueing the work that reads the last batch: records, on every stream that reads it (the
+        pipeline's side streams, or the current stream), the point after which the buffer set may be overwritten.  No
+        stream is made to wait for another here."""
+        sts = list(streams) or [torch.cuda.current_stream(self.device)]
+        evs = []
+        for st in sts:
+            ev = torch.cuda.Event()
+            ev.record(st)
+            evs.append(ev)
+        self.free[self._last] = evs

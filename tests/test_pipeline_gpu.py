@@ -105,12 +105,21 @@ def test_predictor_and_device_stage_fusion():
     kc, off = fused["counts"].cpu().numpy(), fused["offsets"].cpu().numpy()
     for i in range(3):
         b, sc, c = host[i]
-        rows = off[i] + fused["keep"][i, : kc[i]].cpu().numpy()
+        rows = slice(off[i], off[i] + kc[i])     # every route: image i's fused rows are [offsets[i], +counts[i])
         assert kc[i] == len(sc), i
         np.testing.assert_allclose(fused["scores"][rows].cpu().numpy(), sc.numpy(), rtol=1e-6)
         np.testing.assert_array_equal(fused["classes"][rows].cpu().numpy(), np.asarray(c, dtype=np.float32))
         np.testing.assert_allclose(fused["boxes"][rows].cpu().numpy(), np.asarray(b, dtype=np.float64), rtol=1e-6, atol=1e-4)
     assert kc[1] == int(dets[0]["counts"][1])   # untouched list of the only detector that fired
+    # the evaluation-row form (what crosses ranks) needs no special case for this route
+    rows = LF.fused_rows_device(fused, [10, 11, 12]).cpu().numpy()
+    want = []
+    for i in range(3):
+        b, sc, c = host[i]
+        for bb, ss, cc in zip(np.asarray(b, dtype=np.float64), sc.numpy(), np.asarray(c)):
+            if int(cc) in (0, 1, 2):
+                want.append([10 + i, bb[0], bb[1], bb[2] - bb[0], bb[3] - bb[1], ss, cc])
+    np.testing.assert_allclose(rows, np.asarray(want, dtype=np.float64).reshape(-1, 7), rtol=1e-6, atol=1e-4)
 
 
 def test_frame_pair_pipeline_concurrent_equals_serial():
@@ -257,3 +266,49 @@ def test_full_size_pipeline_deterministic_and_batch_invariant():
     o1 = int(one["offsets"][0])
     for k in ("boxes", "scores", "classes"):
         assert torch.equal(f0[k][o:o + c], one[k][o1:o1 + c]), k
+
+
+def test_staggered_pipeline_with_reallocated_inputs():
+    """A loader that creates and frees its batch tensors every step (the caching allocator may recycle that memory for the
+    next batch while the side streams still read the old one unless the pipeline records the streams): results must equal
+    the serial run for every step."""
+    import proben_amd  # noqa: F401
+    from proben_amd.pipeline import FramePairPipeline, HostFeeder
+    from proben_amd.rcnn import DetectorConfig, GeneralizedRCNN
+    from proben_amd.synthetic import synthetic_images, synthetic_state_dict
+    models = [GeneralizedRCNN(DetectorConfig(), synthetic_state_dict(50, 3, 3, seed=s)) for s in (1, 2)]
+    host = [(synthetic_images(2, 256, 320, seed=20 + i), synthetic_images(2, 256, 320, seed=40 + i)) for i in range(4)]
+    serial = FramePairPipeline(models, concurrent=False)
+    want = []
+    for a, b in host:
+        d, f = serial([torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()], [(256, 320)] * 2, (800, 1000))
+        torch.cuda.synchronize()
+        want.append((d[0], f))
+
+    def same(d, f, wd, wf):     # padded layouts: compare the valid rows only
+        assert torch.equal(d[0]["counts"], wd["counts"]) and torch.equal(f["counts"], wf["counts"])
+        for i, c in enumerate(wd["counts"].tolist()):
+            assert torch.equal(d[0]["boxes"][i, :c], wd["boxes"][i, :c])
+        for o, c in zip(wf["offsets"].tolist(), wf["counts"].tolist()):
+            assert torch.equal(f["scores"][o:o + c], wf["scores"][o:o + c]) and torch.equal(f["boxes"][o:o + c], wf["boxes"][o:o + c])
+    pipe = FramePairPipeline(models, concurrent=True, staggered=True)
+    got = []
+    for a, b in host:
+        fa, fb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()     # fresh allocations every step ...
+        got.append(pipe([fa, fb], [(256, 320)] * 2, (800, 1000)))
+        del fa, fb                                                           # ... freed while the side streams still read them
+        junk = torch.full((2, 256, 320, 3), 255, dtype=torch.uint8, device="cuda")   # tries to reuse the freed blocks
+        del junk
+    pipe.wait(got[-1])
+    torch.cuda.synchronize()
+    for (d, f), (wd, wf) in zip(got, want):
+        same(d, f, wd, wf)
+    # the pinned-memory double-buffered uploader feeds the same pipeline
+    feeder = HostFeeder(lambda it=iter(host * 2): [torch.from_numpy(x).pin_memory() for x in next(it)], "cuda")
+    for i in range(4):
+        batch = feeder.next()
+        d, f = pipe(batch, [(256, 320)] * 2, (800, 1000))
+        feeder.mark_consumed(*pipe.streams)
+        pipe.wait((d, f))
+        torch.cuda.synchronize()
+        same(d, f, *want[i])
