@@ -220,6 +220,16 @@ int pe_gather_boxes(const float* boxes, const float* scores, const int32_t* keep
                     int32_t N, int32_t n_in, int32_t max_out, float* out_boxes, float* out_scores,
                     void* stream);
 
+/* Stand-alone forms of two steps the detector kernels carry fused, because the reference exposes them as Python API:
+ * pe_box2box_apply_deltas: Box2BoxTransform.apply_deltas (modeling/box_regression.py:73-110): deltas [N, 4k] and boxes
+ *   [N,4] -> [N, 4k]; weights_host = (wx, wy, ww, wh); dw / dh are clamped to scale_clamp before exp.
+ * pe_grid_anchors: DefaultAnchorGenerator.grid_anchors for ONE level (modeling/anchor_generator.py:43-56,120-146):
+ *   cell_anchors [A,4] + shifts (x * stride, y * stride) (+ offset * stride) -> [H*W*A, 4] in (y, x, anchor) order. */
+int pe_box2box_apply_deltas(const float* deltas, const float* boxes, int32_t N, int32_t k, const float* weights_host,
+                            float scale_clamp, float* out, void* stream);
+int pe_grid_anchors(const float* cell_anchors, int32_t num_cell_anchors, int32_t H, int32_t W, int32_t stride,
+                    float offset, float* out, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * ROIAlign forward over NHWC feature maps.  Replaces roi_align_forward of detectron2._C
  * (layers/csrc/ROIAlign/ROIAlign.h:54-84, ROIAlign_cuda.cu:12-139,310-366; same arithmetic as

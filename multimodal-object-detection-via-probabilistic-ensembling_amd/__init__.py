@@ -23,4 +23,8 @@ def __getattr__(name):  # heavier modules load lazily
     if name == "GeneralizedRCNN":
         from .rcnn import GeneralizedRCNN
         return GeneralizedRCNN
+    if name in ("build_model", "Registry", "META_ARCH_REGISTRY", "Box2BoxTransform", "DefaultAnchorGenerator", "ShapeSpec",
+                "DetectionCheckpointer", "ResizeShortestEdge"):
+        from . import modeling
+        return getattr(modeling, name)
     raise AttributeError(name)

@@ -32,6 +32,8 @@ SIGNATURES = {
     "pe_nms_batched": [c_void_p] * 5 + [c_int, c_int, c_float, c_int, c_int] + [c_void_p] * 3 + [c_size_t, c_void_p],
     "pe_rpn_select_topk": [c_void_p] * 4 + [c_int] * 4 + [c_void_p, c_float] + [c_void_p] * 4 + [c_int, c_void_p, c_size_t, c_void_p],
     "pe_rpn_scratch_bytes": [c_void_p, c_int, c_int],
+    "pe_box2box_apply_deltas": [c_void_p] * 2 + [c_int] * 2 + [c_void_p, c_float, c_void_p, c_void_p],
+    "pe_grid_anchors": [c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p],
     "pe_gather_boxes": [c_void_p] * 4 + [c_int] * 3 + [c_void_p] * 3,
     "pe_roi_align_nhwc": [c_void_p] * 3 + [c_int] * 4 + [c_void_p] + [c_int] * 3 + [c_void_p] + [c_int] * 4 + [c_void_p] * 3,
     "pe_boxhead_candidates": [c_void_p, c_int, c_int, c_int, c_int] + [c_void_p] * 4 + [c_float, c_float, c_int] + [c_void_p] * 7,

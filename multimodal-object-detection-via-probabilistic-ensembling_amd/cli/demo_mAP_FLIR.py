@@ -25,7 +25,12 @@ def main(cmd=None):
     predictor = DefaultPredictor(cfg)
 
     def mapper(d):
-        img = read_image(d["file_name"], cfg.INPUT.FORMAT)
+        # the reference registers <val>/thermal_8_bit/ as image root (demo_mAP_FLIR.py:27-31) while the pairs json of
+        # demo_FLIR_save_predictions.py:95 names files "thermal_8_bit/<stem>.jpeg": accept both spellings
+        path = d["file_name"]
+        if not os.path.exists(path):
+            path = os.path.join(args.dataset_path, "thermal_8_bit", os.path.basename(path))
+        img = read_image(path, cfg.INPUT.FORMAT)
         return {"image_np": img, "height": d["height"], "width": d["width"], "image_id": d["image_id"], "file_name": d["file_name"]}
 
     def model(inputs):

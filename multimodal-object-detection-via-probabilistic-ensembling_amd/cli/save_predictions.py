@@ -4,14 +4,14 @@ on the GPU, images sharded over ranks) and write val_<method>_predictions.json i
     python -m proben_amd.cli.save_predictions --dataset_path DATA/FLIR/val --fusion_method thermal_only \
         --model_path model.pth --prediction_path out/ [--batch 16]
 Input building per method follows :98-121 (early: B,G,R,T(ch 0); middle: B,G,R,T,T,T; RGB resized to the
-thermal size, bilinear)."""
+thermal size with OpenCV's 2x2-tap bilinear rule, data.cv2_linear_resize_u8)."""
 import json
 import os
 
 import numpy as np
 
 from .. import comm, get_cfg
-from ..data import read_image
+from ..data import cv2_linear_resize_u8, read_image
 from ..late_fusion import predictions_to_j1, write_j1
 from ..opt import config_parser
 
@@ -39,8 +39,9 @@ def build_cfg(args, config_dir=None):
 
 
 def resize_bilinear(img, hw):
-    from PIL import Image
-    return np.asarray(Image.fromarray(img).resize((hw[1], hw[0]), Image.BILINEAR))
+    """RGB frame -> thermal frame size with OpenCV's 8-bit INTER_LINEAR rule (what `cv2.resize(rgb, size, cv2.INTER_CUBIC)`
+    at demo_FLIR_save_predictions.py:109 really computes: the flag sits in the `dst` slot)."""
+    return cv2_linear_resize_u8(img, hw[0], hw[1])
 
 
 def load_input(method, rgb_file, thermal_file):

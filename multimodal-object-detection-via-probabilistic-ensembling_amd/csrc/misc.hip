@@ -268,3 +268,63 @@ extern "C" int pe_subsample2_nhwc(const void* in, void* out, int32_t N, int32_t 
     PE_CHECK_LAUNCH("pe_subsample2_nhwc");
     return PE_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Stand-alone forms of two pieces the detector kernels carry fused (rpn.hip decodes only survivors against analytic
+// anchors; boxhead.hip decodes per class): the reference exposes them as Python API, so they exist as ops too.
+// Compiled with -ffp-contract=off: the expressions round like the reference's separate torch ops.
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+__global__ void apply_deltas_kernel(const float* deltas, const float* boxes, int N, int k, float wx, float wy, float ww,
+                                    float wh, float clamp, float* out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= N * k) return;
+    const int n = idx / k;
+    const float* b = boxes + (size_t)n * 4;
+    const float* d = deltas + (size_t)idx * 4;
+    const float wd = b[2] - b[0], ht = b[3] - b[1];
+    const float cx = b[0] + 0.5f * wd, cy = b[1] + 0.5f * ht;
+    const float dx = d[0] / wx, dy = d[1] / wy;
+    const float dw = fminf(d[2] / ww, clamp), dh = fminf(d[3] / wh, clamp);
+    const float pcx = dx * wd + cx, pcy = dy * ht + cy;
+    const float pw = expf(dw) * wd, ph = expf(dh) * ht;
+    float* o = out + (size_t)idx * 4;
+    o[0] = pcx - 0.5f * pw;
+    o[1] = pcy - 0.5f * ph;
+    o[2] = pcx + 0.5f * pw;
+    o[3] = pcy + 0.5f * ph;
+}
+
+__global__ void grid_anchors_kernel(const float* cell, int A, int H, int W, float stride, float offset, float* out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= H * W * A) return;
+    const int a = idx % A, x = (idx / A) % W, y = idx / (A * W);
+    const float sx = offset * stride + (float)x * stride, sy = offset * stride + (float)y * stride;   // arange(offset*stride, ..., step=stride)
+    float* o = out + (size_t)idx * 4;
+    o[0] = sx + cell[a * 4 + 0];
+    o[1] = sy + cell[a * 4 + 1];
+    o[2] = sx + cell[a * 4 + 2];
+    o[3] = sy + cell[a * 4 + 3];
+}
+}  // namespace
+
+extern "C" int pe_box2box_apply_deltas(const float* deltas, const float* boxes, int32_t N, int32_t k, const float* weights_host,
+                                       float scale_clamp, float* out, void* stream) {
+    PE_CHECK_ARG(N >= 0 && k >= 1 && weights_host, "pe_box2box_apply_deltas: bad args");
+    if (N == 0) return PE_OK;
+    PE_CHECK_ARG(deltas && boxes && out, "pe_box2box_apply_deltas: null pointer");
+    hipLaunchKernelGGL(apply_deltas_kernel, dim3(pe::ceil_div((long long)N * k, 256)), dim3(256), 0, (hipStream_t)stream, deltas, boxes, N, k,
+                       weights_host[0], weights_host[1], weights_host[2], weights_host[3], scale_clamp, out);
+    PE_CHECK_LAUNCH("pe_box2box_apply_deltas");
+    return PE_OK;
+}
+
+extern "C" int pe_grid_anchors(const float* cell_anchors, int32_t num_cell_anchors, int32_t H, int32_t W, int32_t stride,
+                               float offset, float* out, void* stream) {
+    PE_CHECK_ARG(cell_anchors && out && num_cell_anchors >= 1 && H >= 0 && W >= 0 && stride > 0, "pe_grid_anchors: bad args");
+    if (H * W == 0) return PE_OK;
+    hipLaunchKernelGGL(grid_anchors_kernel, dim3(pe::ceil_div((long long)H * W * num_cell_anchors, 256)), dim3(256), 0,
+                       (hipStream_t)stream, cell_anchors, num_cell_anchors, H, W, (float)stride, offset, out);
+    PE_CHECK_LAUNCH("pe_grid_anchors");
+    return PE_OK;
+}

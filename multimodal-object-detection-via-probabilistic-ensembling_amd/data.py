@@ -84,8 +84,11 @@ def register_coco_instances(name, metadata, json_file, image_root):
 
 
 def resize_shortest_edge_shape(h, w, short_edge_length=800, max_size=1333):
-    """ResizeShortestEdge.get_transform: short side -> 800 capped so the long side <= 1333, round half up."""
+    """ResizeShortestEdge.get_transform (transform_gen.py:192-213): short side -> 800 capped so the long side <= 1333,
+    round half up; short_edge_length 0 = NoOpTransform (the image keeps its size)."""
     size = short_edge_length
+    if size == 0:
+        return int(h), int(w)
     scale = size * 1.0 / min(h, w)
     if h < w:
         newh, neww = size, scale * w
@@ -127,6 +130,69 @@ def pil_bilinear_tables(in_size, out_size):
     tab[:, 0], tab[:, 1] = xmin, n
     tab[:, 2:] = np.trunc(0.5 + w * float(1 << PIL_PRECISION_BITS)).astype(np.int32)
     return tab
+
+
+def cv2_linear_resize_u8(img, new_h, new_w):
+    """cv2.resize(img, (new_w, new_h)) with the default INTER_LINEAR on a uint8 [H, W, C] image: the resize the
+    reference applies to the RGB frame before stacking it with the thermal one
+    (demo/FLIR/demo_FLIR_save_predictions.py:109 - the `cv2.INTER_CUBIC` argument lands in the `dst` slot, so the
+    interpolation is the default bilinear).  2 x 2 taps, NO antialiasing - unlike Pillow's BILINEAR, whose
+    support grows with the down-scale factor.  OpenCV is a third-party dependency that is absent offline (4.6.0 in
+    probEn.yml): this restates its published 8-bit rule - half-pixel source coordinates, 11-bit fixed-point
+    coefficients (cvRound(w * 2048), saturated to int16), horizontal pass in int32, vertical pass
+    ((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2 - PARITY UNPINNED (no OpenCV to check against)."""
+    img = np.asarray(img)
+    assert img.dtype == np.uint8 and img.ndim == 3
+    h, w = img.shape[:2]
+    if (h, w) == (new_h, new_w):
+        return img.copy()
+
+    def taps(n_in, n_out):
+        scale = n_in / n_out
+        f = (np.arange(n_out, dtype=np.float64) + 0.5) * scale - 0.5
+        i0 = np.floor(f).astype(np.int64)
+        a = (f - i0).astype(np.float32)
+        lo = i0 < 0
+        a[lo], i0[lo] = 0.0, 0
+        hi = i0 >= n_in - 1
+        a[hi], i0[hi] = 0.0, n_in - 1
+        i1 = np.minimum(i0 + 1, n_in - 1)
+        c1 = np.clip(np.rint(a.astype(np.float64) * 2048.0), -32768, 32767).astype(np.int32)   # cvRound: half to even
+        c0 = np.clip(np.rint((1.0 - a).astype(np.float64) * 2048.0), -32768, 32767).astype(np.int32)
+        return i0, i1, c0, c1
+    x0, x1, ax0, ax1 = taps(w, new_w)
+    y0, y1, by0, by1 = taps(h, new_h)
+    src = img.astype(np.int32)
+    rows = src[:, x0] * ax0[None, :, None] + src[:, x1] * ax1[None, :, None]          # [h, new_w, C], scaled by 2^11
+    r0, r1 = rows[y0] >> 4, rows[y1] >> 4
+    out = (((by0[:, None, None] * r0) >> 16) + ((by1[:, None, None] * r1) >> 16) + 2) >> 2
+    return np.clip(out, 0, 255).astype(np.uint8)
+
+
+def cv2_linear_resize_f(img, new_h, new_w):
+    """cv2.resize(img, (new_w, new_h)) default INTER_LINEAR on a floating-point [H, W, C] image (the reference's branch
+    for 4- / 6-channel inputs, transform.py:82-91): half-pixel coordinates computed in double and cast to float, float
+    weights, horizontal then vertical pass in the image's dtype.  PARITY UNPINNED (OpenCV absent); the GPU preprocess
+    kernel (pe_preprocess_pack, src_kind 1) and oracle/resize.py follow the same rule."""
+    img = np.asarray(img)
+    h, w = img.shape[:2]
+    dt = img.dtype if img.dtype in (np.float32, np.float64) else np.float64
+
+    def taps(n_in, n_out):
+        scale = n_in / n_out
+        f = (np.arange(n_out, dtype=np.float64) + 0.5) * scale - 0.5
+        i0 = np.floor(f).astype(np.int64)
+        a = (f - i0).astype(np.float32)
+        lo = i0 < 0
+        a[lo], i0[lo] = 0.0, 0
+        hi = i0 >= n_in - 1
+        a[hi], i0[hi] = 0.0, n_in - 1
+        return i0, np.minimum(i0 + 1, n_in - 1), (np.float32(1.0) - a), a
+    x0, x1, ax0, ax1 = taps(w, new_w)
+    y0, y1, by0, by1 = taps(h, new_h)
+    src = img.astype(dt)
+    rows = src[:, x0] * ax0[None, :, None].astype(dt) + src[:, x1] * ax1[None, :, None].astype(dt)
+    return rows[y0] * by0[:, None, None].astype(dt) + rows[y1] * by1[:, None, None].astype(dt)
 
 
 class InferenceSampler:

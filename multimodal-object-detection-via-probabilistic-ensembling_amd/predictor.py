@@ -50,10 +50,18 @@ class DefaultPredictor:
             raise _lib.HipLibraryError(
                 f"MODEL.DEVICE={self.cfg.MODEL.DEVICE}: proben_amd ships the MI355X path only (no CPU fallback); "
                 "the CPU restatement of the reference lives in oracle/ as test infrastructure.")
+        from .modeling import META_ARCH_REGISTRY, ResizeShortestEdge
+        META_ARCH_REGISTRY.get(self.cfg.MODEL.META_ARCHITECTURE)      # unknown architectures fail like build_model(cfg)
+        # build_model(cfg) + DetectionCheckpointer(model).load(cfg.MODEL.WEIGHTS) of defaults.py:161-168 in one step (the
+        # weights are packed for the kernels exactly once)
         self.model = GeneralizedRCNN(detector_config_from_cfg(self.cfg), load_weights(self.cfg))
         self.model.eval()
         self.metadata = MetadataCatalog.get(self.cfg.DATASETS.TEST[0]) if len(self.cfg.DATASETS.TEST) else None
+        mn = self.cfg.INPUT.MIN_SIZE_TEST
+        mn = mn[0] if isinstance(mn, (list, tuple)) else mn
+        self.transform_gen = ResizeShortestEdge([mn, mn], self.cfg.INPUT.MAX_SIZE_TEST)      # defaults.py:170-172
         self.input_format = self.cfg.INPUT.FORMAT
+        assert self.input_format in ["RGB", "BGR", "BGRT", "BGRTTT"], self.input_format
         self.min_size, self.max_size = self.model.cfg.min_size_test, self.model.cfg.max_size_test
 
     def _to_device(self, img):

@@ -83,6 +83,18 @@ class GeneralizedRCNN:
     def eval(self):
         return self
 
+    def load_state_dict(self, state_dict, strict=True):
+        """Re-pack a reference-format state dict into the device tensors the kernels read (what
+        DetectionCheckpointer(model).load(path) ends in)."""
+        w = PackedDetector(state_dict, self.device, self.cfg.num_classes)
+        assert w.depth == self.depth or not strict, f"state dict is ResNet-{w.depth}, model was built as ResNet-{self.depth}"
+        self.w, self.depth = w, w.depth
+        return self
+
+    def to(self, device):
+        assert torch.device(device).type == "cuda", "proben_amd.GeneralizedRCNN lives on the GPU (no CPU fallback)"
+        return self
+
     # ------------------------------------------------------------------ stages
     def _conv(self, x, name, **kw):
         w, b = self.w.convs[name]
@@ -161,14 +173,15 @@ class GeneralizedRCNN:
         batches = []
         for ch0, nch in groups:
             x = torch.empty((N, Hp, Wp, 4), dtype=torch.float16, device=self.device)
+            sd0 = 0 if ch0 == 3 else ch0    # BGRTTT: the thermal half divides by PIXEL_STD[:3] (meta_arch/rcnn.py:63-66)
             for i, im in enumerate(images):
                 if kinds[i] == 0 and C == 3 and tuple(sizes[i]) != tuple(im.shape[:2]):
                     # 3-channel uint8 + resize: the reference goes through Pillow (transform.py:92-97) - exact restatement
                     L.preprocess_pack_pil_u8(im.contiguous(), x[i], ch0=ch0, nch=nch, flip_rgb=False, dst_hw=sizes[i],
-                                             mean=mean[ch0:ch0 + nch], std=std[ch0:ch0 + nch])
+                                             mean=mean[ch0:ch0 + nch], std=std[sd0:sd0 + nch])
                     continue
                 L.preprocess_pack(im.contiguous(), x[i], src_kind=kinds[i], ch0=ch0, nch=nch, flip_rgb=False,
-                                  dst_hw=sizes[i], mean=mean[ch0:ch0 + nch], std=std[ch0:ch0 + nch])
+                                  dst_hw=sizes[i], mean=mean[ch0:ch0 + nch], std=std[sd0:sd0 + nch])
             batches.append(x)
         return batches, sizes
 
@@ -188,13 +201,14 @@ class GeneralizedRCNN:
         batches = []
         for ch0, nch in ([(0, min(C, 4))] if C <= 4 else [(0, 3), (3, 3)]):
             x = torch.empty((N, Hp, Wp, 4), dtype=torch.float16, device=self.device)
+            sd0 = 0 if ch0 == 3 else ch0    # BGRTTT: thermal half uses PIXEL_STD[:3] (meta_arch/rcnn.py:63-66)
             if kind == 0 and C == 3 and tuple(size) != (h, w):   # Pillow-exact resize (see _preprocess)
                 L.preprocess_pack_pil_u8(images.contiguous(), x, ch0=ch0, nch=nch, flip_rgb=False, dst_hw=size,
-                                         mean=mean[ch0:ch0 + nch], std=std[ch0:ch0 + nch])
+                                         mean=mean[ch0:ch0 + nch], std=std[sd0:sd0 + nch])
                 batches.append(x)
                 continue
             L.preprocess_pack_batch(images.contiguous(), x, src_kind=kind, ch0=ch0, nch=nch, flip_rgb=False, dst_hw=size,
-                                    mean=mean[ch0:ch0 + nch], std=std[ch0:ch0 + nch])
+                                    mean=mean[ch0:ch0 + nch], std=std[sd0:sd0 + nch])
             batches.append(x)
         return batches, [size] * N
 
