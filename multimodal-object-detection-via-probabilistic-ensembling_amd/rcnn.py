@@ -212,13 +212,19 @@ class GeneralizedRCNN:
             batches.append(x)
         return batches, [size] * N
 
-    def _rpn(self, feats, sizes_dev, N):
+    def _rpn(self, feats, sizes_dev, N, heads=None):
+        """heads (tests): precomputed fp32 RPN head outputs [N,H,W,16] per level (3 objectness + 12 deltas) instead of
+        running the head convolutions - lets the discrete chain be checked on the oracle's own fp32 numbers."""
         cfg = self.cfg
-        heads, hw, strides = [], [], [4, 8, 16, 32, 64]
+        hw, strides = [], [4, 8, 16, 32, 64]
+        if heads is None:
+            heads = []
+            for f in feats:
+                t = self._conv(f, "rpn.conv", kernel=3, relu=True)
+                w, b = self.w.convs["rpn.head"]
+                heads.append(L.conv2d_nhwc(t, w, b, kernel=1, out_f32=True, cout=15, cout_store=15, out_stride=16))
+        feats = heads
         for f in feats:
-            t = self._conv(f, "rpn.conv", kernel=3, relu=True)
-            w, b = self.w.convs["rpn.head"]
-            heads.append(L.conv2d_nhwc(t, w, b, kernel=1, out_f32=True, cout=15, cout_store=15, out_stride=16))
             hw += [f.shape[1], f.shape[2]]
         nl = len(feats)
         topk = [min(cfg.pre_nms_topk, f.shape[1] * f.shape[2] * 3) for f in feats]
@@ -246,17 +252,21 @@ class GeneralizedRCNN:
         _lib.check(st, "pe_gather_boxes")
         return props, plog, kcnt, heads
 
-    def _roi_heads(self, feats, props, pcnt, sizes_dev, out_dev, N):
+    def _roi_heads(self, feats, props, pcnt, sizes_dev, out_dev, N, head=None):
+        """head (tests): precomputed fp32 predictor outputs [N*P, head_stride] (K+1 logits, 4K deltas, log-variance)
+        instead of ROIAlign + the FC layers."""
         cfg, w = self.cfg, self.w
         P = cfg.post_nms_topk
         K = cfg.num_classes
         dev = self.device
-        C = feats[0].shape[3]
-        pooled = L.roi_align_nhwc(feats[:4], props, scales=[1 / 4, 1 / 8, 1 / 16, 1 / 32], pooled=(7, 7),
-                                  sampling_ratio=0, aligned=True, counts=pcnt, per_image=P, num_rois=N * P)
-        x = L.linear_f16(pooled.view(N * P, 49 * C), w.fc1[0], w.fc1[1], relu=True)
-        x = L.linear_f16(x, w.fc2[0], w.fc2[1], relu=True)
-        head = L.linear_f16(x, w.predictor[0], w.predictor[1], out_f32=True, cout_store=w.head_cols, out_stride=w.head_stride)
+        pooled = None
+        if head is None:
+            C = feats[0].shape[3]
+            pooled = L.roi_align_nhwc(feats[:4], props, scales=[1 / 4, 1 / 8, 1 / 16, 1 / 32], pooled=(7, 7),
+                                      sampling_ratio=0, aligned=True, counts=pcnt, per_image=P, num_rois=N * P)
+            x = L.linear_f16(pooled.view(N * P, 49 * C), w.fc1[0], w.fc1[1], relu=True)
+            x = L.linear_f16(x, w.fc2[0], w.fc2[1], relu=True)
+            head = L.linear_f16(x, w.predictor[0], w.predictor[1], out_f32=True, cout_store=w.head_cols, out_stride=w.head_stride)
         cmax = min(P * K, 16384)
         cb = torch.empty((N, cmax, 4), dtype=torch.float32, device=dev)
         cs = torch.empty((N, cmax), dtype=torch.float32, device=dev)
