@@ -253,6 +253,8 @@ int pe_roi_align_nhwc(const void* const* feats_host, const int32_t* feat_hw_host
  * [0,K] logits, [K+1,5K] deltas (class-major), 5K+1 log-variance.
  *   pe_boxhead_candidates: softmax, decode (weights reg_weights_host[4]), finite mask, clip to image_hw,
  *     score > thresh -> candidates in (row, class) order: boxes, scores, class, (filtered row, original row).
+ *     At most cand_max candidates per image are kept (proposal-row order); cand_total (optional, may be NULL) receives
+ *     the uncapped number so a caller can detect - and refuse - an overflow instead of losing detections silently.
  *   (caller runs pe_nms_batched over the candidates, class-aware, max_out = max_det)
  *   pe_boxhead_finalize: gathers the kept candidates' fields (incl. the reference's Q3/Q4 index quirks;
  *     fix_vars != 0 pairs each detection with its own proposal's variance), rescales to out_hw, clips,
@@ -262,8 +264,8 @@ int pe_boxhead_candidates(const float* head, int32_t head_stride, int32_t N, int
                           int32_t num_classes, const int32_t* prop_counts, const float* proposals,
                           const int32_t* image_hw, const float* reg_weights_host, float scale_clamp,
                           float score_thresh, int32_t cand_max, float* cand_boxes, float* cand_scores,
-                          int32_t* cand_class, int32_t* cand_rows, int32_t* cand_counts, float* probs,
-                          void* stream);
+                          int32_t* cand_class, int32_t* cand_rows, int32_t* cand_counts, int32_t* cand_total,
+                          float* probs, void* stream);
 int pe_boxhead_finalize(const float* head, int32_t head_stride, int32_t N, int32_t per_image,
                         int32_t num_classes, int32_t cand_max, int32_t max_det, int32_t fix_vars,
                         const float* probs, const float* cand_boxes, const float* cand_scores,

@@ -31,6 +31,7 @@ struct BoxHeadArgs {
     int32_t* cand_class;   // [N, cand_max]
     int32_t* cand_rows;    // [N, cand_max, 2] (filtered row id, original row id)
     int32_t* cand_counts;  // [N]
+    int32_t* cand_total;   // [N] optional: candidates BEFORE the cand_max cap (overflow = cand_total > cand_max)
     float* probs;          // [N, per_image, K+1] scratch
 };
 
@@ -100,7 +101,10 @@ __global__ __launch_bounds__(kThreads) void boxhead_candidates_kernel(BoxHeadArg
     int tot_valid, tot_cand;
     const int frow = block_exclusive_scan(valid ? 1 : 0, wave_tot, tot_valid);
     int cbase = block_exclusive_scan(npass, wave_tot, tot_cand);
-    if (threadIdx.x == 0) a.cand_counts[n] = min(tot_cand, a.cand_max);
+    if (threadIdx.x == 0) {
+        a.cand_counts[n] = min(tot_cand, a.cand_max);
+        if (a.cand_total) a.cand_total[n] = tot_cand;
+    }
     if (valid) {
         for (int k = 0; k < K; ++k) {
             if (!(pr[k] > a.score_thresh)) continue;
@@ -189,8 +193,8 @@ extern "C" int pe_boxhead_candidates(const float* head, int32_t head_stride, int
                                      int32_t num_classes, const int32_t* prop_counts, const float* proposals,
                                      const int32_t* image_hw, const float* reg_weights_host, float scale_clamp,
                                      float score_thresh, int32_t cand_max, float* cand_boxes, float* cand_scores,
-                                     int32_t* cand_class, int32_t* cand_rows, int32_t* cand_counts, float* probs,
-                                     void* stream) {
+                                     int32_t* cand_class, int32_t* cand_rows, int32_t* cand_counts, int32_t* cand_total,
+                                     float* probs, void* stream) {
     PE_CHECK_ARG(head && proposals && image_hw && reg_weights_host, "pe_boxhead_candidates: null pointer");
     PE_CHECK_ARG(cand_boxes && cand_scores && cand_class && cand_rows && cand_counts && probs,
                  "pe_boxhead_candidates: null output");
@@ -206,7 +210,7 @@ extern "C" int pe_boxhead_candidates(const float* head, int32_t head_stride, int
     a.wx = reg_weights_host[0]; a.wy = reg_weights_host[1]; a.ww = reg_weights_host[2]; a.wh = reg_weights_host[3];
     a.scale_clamp = scale_clamp; a.score_thresh = score_thresh; a.cand_max = cand_max;
     a.cand_boxes = cand_boxes; a.cand_scores = cand_scores; a.cand_class = cand_class; a.cand_rows = cand_rows;
-    a.cand_counts = cand_counts; a.probs = probs;
+    a.cand_counts = cand_counts; a.cand_total = cand_total; a.probs = probs;
     hipLaunchKernelGGL(boxhead_candidates_kernel, dim3(N), dim3(kThreads), 0, (hipStream_t)stream, a);
     PE_CHECK_LAUNCH("pe_boxhead_candidates");
     return PE_OK;

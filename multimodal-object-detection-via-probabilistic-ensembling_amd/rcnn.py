@@ -267,17 +267,20 @@ class GeneralizedRCNN:
             x = L.linear_f16(pooled.view(N * P, 49 * C), w.fc1[0], w.fc1[1], relu=True)
             x = L.linear_f16(x, w.fc2[0], w.fc2[1], relu=True)
             head = L.linear_f16(x, w.predictor[0], w.predictor[1], out_f32=True, cout_store=w.head_cols, out_stride=w.head_stride)
-        cmax = min(P * K, 16384)
+        # a proposal can pass the threshold in at most ceil(1/thr) - 1 classes (softmax sums to 1): never size beyond that
+        per_prop = min(K, max(1, int(math.ceil(1.0 / max(cfg.score_thresh, 1e-6))) - 1))
+        cmax = min(P * per_prop, 16384)   # 16384 = pe_nms_batched's row limit; overflow is REPORTED (cand_total), not silent
         cb = torch.empty((N, cmax, 4), dtype=torch.float32, device=dev)
         cs = torch.empty((N, cmax), dtype=torch.float32, device=dev)
         cc = torch.empty((N, cmax), dtype=torch.int32, device=dev)
         cr = torch.empty((N, cmax, 2), dtype=torch.int32, device=dev)
         ccnt = torch.empty((N,), dtype=torch.int32, device=dev)
+        ctot = torch.empty((N,), dtype=torch.int32, device=dev)
         probs = torch.empty((N, P, K + 1), dtype=torch.float32, device=dev)
         lib = _lib.lib()
         st = lib.pe_boxhead_candidates(_lib.ptr(head), w.head_stride, N, P, K, _lib.ptr(pcnt), _lib.ptr(props),
                                        _lib.ptr(sizes_dev), self._reg_w, SCALE_CLAMP, cfg.score_thresh, cmax,
-                                       _lib.ptr(cb), _lib.ptr(cs), _lib.ptr(cc), _lib.ptr(cr), _lib.ptr(ccnt),
+                                       _lib.ptr(cb), _lib.ptr(cs), _lib.ptr(cc), _lib.ptr(cr), _lib.ptr(ccnt), _lib.ptr(ctot),
                                        _lib.ptr(probs), _lib.stream())
         _lib.check(st, "pe_boxhead_candidates")
         D = cfg.detections_per_image
@@ -301,6 +304,7 @@ class GeneralizedRCNN:
         _lib.check(st, "pe_boxhead_finalize")
         det["_head"] = head
         det["_pooled"] = pooled
+        det["cand_total"], det["cand_max"] = ctot, cmax
         return det
 
     # ------------------------------------------------------------------ public API
@@ -340,6 +344,10 @@ class GeneralizedRCNN:
     def to_instances(self, det):
         """Device result dict -> list[{"instances": Instances}] (one host sync)."""
         counts = det["counts"].cpu().tolist()
+        if "cand_total" in det and int(det["cand_total"].max()) > det["cand_max"]:
+            raise RuntimeError(f"box head: {int(det['cand_total'].max())} (proposal, class) candidates pass SCORE_THRESH_TEST="
+                               f"{self.cfg.score_thresh} on one image but the NMS stage holds {det['cand_max']}: detections would be "
+                               "dropped in proposal order (the reference keeps all).  Raise the threshold or lower POST_NMS_TOPK_TEST.")
         cfg = self.cfg
         out = []
         for n, c in enumerate(counts):

@@ -469,12 +469,22 @@ def test_boxhead_matches_oracle_quirks():
     hd, pr = head.view(N * P, stride).cuda(), props.cuda()
     cb = torch.empty(N, cmax, 4, device=dev); cs = torch.empty(N, cmax, device=dev)
     cc = torch.empty(N, cmax, dtype=torch.int32, device=dev); cr = torch.empty(N, cmax, 2, dtype=torch.int32, device=dev)
-    ccnt = torch.empty(N, dtype=torch.int32, device=dev); probs = torch.empty(N, P, K + 1, device=dev)
+    ccnt = torch.empty(N, dtype=torch.int32, device=dev); ctot = torch.empty(N, dtype=torch.int32, device=dev); probs = torch.empty(N, P, K + 1, device=dev)
     sz = torch.tensor(sizes, dtype=torch.int32, device=dev); osz = torch.tensor(outs, dtype=torch.int32, device=dev)
     lib = _lib.lib()
     _lib.check(lib.pe_boxhead_candidates(_lib.ptr(hd), stride, N, P, K, _lib.ptr(pcnt.cuda()), _lib.ptr(pr), _lib.ptr(sz),
                                          (ctypes.c_float * 4)(10, 10, 5, 5), SCALE_CLAMP, 0.5, cmax, _lib.ptr(cb), _lib.ptr(cs),
-                                         _lib.ptr(cc), _lib.ptr(cr), _lib.ptr(ccnt), _lib.ptr(probs), _lib.stream()), "cand")
+                                         _lib.ptr(cc), _lib.ptr(cr), _lib.ptr(ccnt), _lib.ptr(ctot), _lib.ptr(probs), _lib.stream()), "cand")
+    assert torch.equal(ctot, ccnt)                       # no overflow here: the uncapped total equals the kept count
+    # a cap smaller than the candidates is REPORTED: kept count = cap, total = the real number
+    small = 3
+    sb_, ss_, sc_, sr_ = cb[:, :small].contiguous(), cs[:, :small].contiguous(), cc[:, :small].contiguous(), cr[:, :small].contiguous()
+    c2, t2 = torch.empty_like(ccnt), torch.empty_like(ctot)
+    _lib.check(lib.pe_boxhead_candidates(_lib.ptr(hd), stride, N, P, K, _lib.ptr(pcnt.cuda()), _lib.ptr(pr), _lib.ptr(sz),
+                                         (ctypes.c_float * 4)(10, 10, 5, 5), SCALE_CLAMP, 0.5, small, _lib.ptr(sb_), _lib.ptr(ss_),
+                                         _lib.ptr(sc_), _lib.ptr(sr_), _lib.ptr(c2), _lib.ptr(t2), _lib.ptr(torch.empty_like(probs)),
+                                         _lib.stream()), "cand-small")
+    assert torch.equal(t2, ctot) and torch.equal(c2, ctot.clamp(max=small))
     keep, kcnt = L.nms_batched_raw(cb, cs, cc, ccnt, None, 0.5, 0, 100)
     D_ = 100
     o = {k: torch.empty(s, dtype=t, device=dev) for k, s, t in [
