@@ -42,6 +42,9 @@ struct ConvWdArgs {
     int out_stride;  // halfs between output pixels
     int seg, nseg;   // image-row segment length of a block tile and segments per tile
     int tiles_m, tiles_n;
+    // 1x1 lab kernel only (scripts/lab/conv_wd_1x1.h)
+    int stride, Ho, Wo;          // output grid (stride 1 | 2)
+    int res_mode, resH, resW;    // 0 none, 1 residual has the output's shape, 2 residual [N,resH,resW,Cout] read at (oh/2, ow/2)
 };
 }  // namespace pe
 
@@ -266,6 +269,7 @@ __global__ __launch_bounds__(64 * WM * WN, (TPX <= 4 ? 2 : 1)) void conv3x3_wd_k
             }
     }
 }
+
 
 // packing: [Cout][3][3][Cin] (or [Cout][K] for 1x1 with order = 0) -> fragment records
 __global__ void pack_weights_kernel(const _Float16* w, _Float16* out, int Cout, int K, int Cin, int WN, int is3x3) {

@@ -1,7 +1,8 @@
 // Stand-alone probe of the weights-direct convolution kernels (csrc/conv_wd.h) + the MFMA yardstick.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -I multimodal-object-detection-via-probabilistic-ensembling_amd/csrc \
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -I scripts -I multimodal-object-detection-via-probabilistic-ensembling_amd/csrc \
 //         scripts/conv_wd_probe.hip -o scripts/conv_wd_probe && scripts/conv_wd_probe
 #include "conv_wd.h"
+#include "lab/conv_wd_1x1.h"
 
 #include <cmath>
 #include <cstdlib>
@@ -151,7 +152,85 @@ void run_variant(const char* name, pe::ConvWdArgs a, const std::vector<_Float16>
     fflush(stdout);
 }
 
+// ---------------- 1x1 probe ----------------
+template <int WM, int WN, int TPX, int DEPTH>
+void run_1x1(const char* name, pe::ConvWdArgs a, const std::vector<_Float16>& hin, const std::vector<_Float16>& hw, const std::vector<float>& hb,
+             const std::vector<_Float16>& hres, std::vector<_Float16>& hout, int reps) {
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipMemset(a.out, 0xff, (size_t)a.M * a.out_stride * 2);
+    int st = wd::launch_conv1x1_wd<WM, WN, TPX, DEPTH>(a, 0);
+    hipError_t err = hipDeviceSynchronize();
+    if (st != 0 || err != hipSuccess) { printf("%-22s failed (%d, %s)\n", name, st, hipGetErrorString(err)); return; }
+    hipMemcpy(hout.data(), a.out, hout.size() * 2, hipMemcpyDeviceToHost);
+    std::mt19937 rng(9);
+    double max_err = 0; int bad = 0;
+    for (int s = 0; s < 3000; ++s) {
+        const int m = s < 200 ? (s < 100 ? s : a.M - 1 - (s - 100)) : (int)(rng() % a.M);
+        const int c = rng() % a.Cout;
+        const int ow = m % a.Wo, oh = (m / a.Wo) % a.Ho, n = m / (a.Wo * a.Ho);
+        const _Float16* x = &hin[((size_t)(n * a.H + oh * a.stride) * a.W + ow * a.stride) * a.Cin];
+        const _Float16* w = &hw[(size_t)c * a.Cin];
+        double ref = hb[c];
+        for (int ci = 0; ci < a.Cin; ++ci) ref += (double)(float)x[ci] * (double)(float)w[ci];
+        if (a.res_mode == 1) ref += (double)(float)hres[(size_t)m * a.Cout + c];
+        if (a.res_mode == 2) ref += (double)(float)hres[(((size_t)n * a.resH + (oh >> 1)) * a.resW + (ow >> 1)) * a.Cout + c];
+        if (a.relu && ref < 0) ref = 0;
+        const double e = fabs((double)(float)hout[(size_t)m * a.out_stride + c] - ref);
+        if (e > max_err) max_err = e;
+        if (e > 2e-2 + 4e-3 * fabs(ref)) ++bad;
+    }
+    for (int i = 0; i < 3; ++i) wd::launch_conv1x1_wd<WM, WN, TPX, DEPTH>(a, 0);
+    hipEventRecord(e0);
+    for (int i = 0; i < reps; ++i) wd::launch_conv1x1_wd<WM, WN, TPX, DEPTH>(a, 0);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    const double ms = time_ms(e0, e1) / reps;
+    const double bytes = 2.0 * ((double)a.M * a.Cin + (double)a.Cout * a.Cin + (double)a.M * a.Cout + (a.res_mode == 1 ? (double)a.M * a.Cout : (a.res_mode == 2 ? (double)a.N * a.resH * a.resW * a.Cout : 0.0)));
+    printf("%-22s %8.4f ms %8.1f TFLOP/s %7.0f GB/s algorithmic   check: %d bad / 3000, max err %.4f\n", name, ms,
+           2.0 * a.M * a.Cout * a.Cin / (ms * 1e-3) / 1e12, bytes / (ms * 1e-3) / 1e9, bad, max_err);
+    fflush(stdout);
+}
+
+void probe_1x1() {
+    struct S { int N, H, W, Cin, Cout, stride, res_mode, relu; const char* what; };
+    const S shapes[] = {{3, 10, 12, 128, 256, 1, 1, 1, "tiny (tail + res)"},
+                        {32, 50, 64, 256, 1024, 1, 1, 1, "res4 conv3 + residual"}, {32, 50, 64, 1024, 256, 1, 0, 1, "res4 conv1"},
+                        {32, 200, 256, 64, 256, 1, 1, 1, "res2 conv3 + residual"}, {32, 100, 128, 128, 512, 1, 1, 1, "res3 conv3 + residual"},
+                        {32, 100, 128, 512, 256, 1, 2, 0, "fpn lateral3 + top-down"}, {32, 100, 128, 512, 1024, 2, 0, 0, "res4 shortcut (stride 2)"},
+                        {32, 25, 32, 2048, 512, 1, 0, 1, "res5 conv1"}, {32000, 1, 1, 1024, 1024, 1, 0, 1, "fc2"}, {32000, 1, 1, 12544, 1024, 1, 0, 1, "fc1"},
+                        {32, 25, 32, 512, 2048, 1, 1, 1, "res5 conv3 + residual"}};
+    for (const S& s : shapes) {
+        const int Ho = (s.H - 1) / s.stride + 1, Wo = (s.W - 1) / s.stride + 1, M = s.N * Ho * Wo;
+        const int rH = (Ho + 1) / 2, rW = (Wo + 1) / 2;
+        std::vector<_Float16> hin((size_t)s.N * s.H * s.W * s.Cin), hw((size_t)s.Cout * s.Cin), hout((size_t)M * s.Cout);
+        std::vector<_Float16> hres(s.res_mode == 1 ? (size_t)M * s.Cout : (s.res_mode == 2 ? (size_t)s.N * rH * rW * s.Cout : 1));
+        std::vector<float> hb(s.Cout);
+        std::mt19937 rng(21);
+        std::normal_distribution<float> nd(0.f, 1.f);
+        for (auto& v : hin) { const float x = nd(rng); v = (_Float16)(x > 0 ? x : 0.f); }
+        for (auto& v : hw) v = (_Float16)(nd(rng) / sqrtf((float)s.Cin));
+        for (auto& v : hres) v = (_Float16)nd(rng);
+        for (auto& v : hb) v = nd(rng) * 0.1f;
+        _Float16 *din, *dw, *dwp, *dout, *dres; float* db;
+        hipMalloc(&din, hin.size() * 2); hipMalloc(&dw, hw.size() * 2); hipMalloc(&dwp, hw.size() * 2);
+        hipMalloc(&dout, hout.size() * 2); hipMalloc(&dres, hres.size() * 2); hipMalloc(&db, hb.size() * 4);
+        hipMemcpy(din, hin.data(), hin.size() * 2, hipMemcpyHostToDevice);
+        hipMemcpy(dw, hw.data(), hw.size() * 2, hipMemcpyHostToDevice);
+        hipMemcpy(dres, hres.data(), hres.size() * 2, hipMemcpyHostToDevice);
+        hipMemcpy(db, hb.data(), hb.size() * 4, hipMemcpyHostToDevice);
+        const long long total = (long long)(s.Cout / 32) * (s.Cin / 16) * 64;
+        hipLaunchKernelGGL(wd::pack_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, 0, dw, dwp, s.Cout, s.Cin, s.Cin, 4, 0);
+        pe::ConvWdArgs a{};
+        a.in = din; a.wpk = dwp; a.bias = db; a.res = s.res_mode ? dres : nullptr; a.out = dout; a.N = s.N; a.H = s.H; a.W = s.W;
+        a.Cin = s.Cin; a.Cout = s.Cout; a.M = M; a.relu = s.relu; a.out_stride = s.Cout; a.stride = s.stride; a.Ho = Ho; a.Wo = Wo;
+        a.res_mode = s.res_mode; a.resH = rH; a.resW = rW;
+        printf("--- 1x1 %s: N%d %dx%d %d->%d s%d res%d\n", s.what, s.N, s.H, s.W, s.Cin, s.Cout, s.stride, s.res_mode);
+        run_1x1<1, 4, 4, 4>("wd1x1<1,4,tpx4>", a, hin, hw, hb, hres, hout, 20);
+        hipFree(din); hipFree(dw); hipFree(dwp); hipFree(dout); hipFree(dres); hipFree(db);
+    }
+}
+
 int main(int argc, char** argv) {
+    if (argc > 1 && atoi(argv[1]) == -1) { probe_1x1(); return 0; }
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     // ---------------- yardstick ----------------
     {

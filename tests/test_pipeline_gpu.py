@@ -314,3 +314,41 @@ def test_staggered_pipeline_with_reallocated_inputs():
         pipe.wait((d, f))
         torch.cuda.synchronize()
         same(d, f, *want[i])
+
+
+def test_config3_three_detector_pipeline_full_size():
+    """BASELINE configs[3] at its real size: thermal (3-ch) + early fusion (4-ch stem) + middle fusion (6-ch: two backbone
+    passes, 512-channel RPN / box head) R101-FPN detectors on 640x512 frames -> 800x1000, 3-way ProbEn (probEn / v-avg):
+    the device-to-device pipeline equals the reference-style route (per-detector prediction lists -> late_fusion driver,
+    demo_probEn.py:198-298), and the evaluation rows a rank would contribute are well formed."""
+    import proben_amd  # noqa: F401
+    from proben_amd import late_fusion as LF
+    from proben_amd.pipeline import FramePairPipeline
+    from proben_amd.rcnn import DetectorConfig, GeneralizedRCNN
+    from proben_amd.synthetic import synthetic_images, synthetic_state_dict
+    B = 4
+    models, frames = [], []
+    for i, (ch, fmt) in enumerate(((3, "BGR"), (4, "BGRT"), (6, "BGRTTT"))):
+        mean = (103.53, 116.28, 123.675) + (135.438,) * (ch - 3)
+        models.append(GeneralizedRCNN(DetectorConfig(input_format=fmt, pixel_mean=mean, pixel_std=(1.0,) * ch),
+                                      synthetic_state_dict(101, 3, ch, seed=i + 1)))
+        frames.append(torch.from_numpy(synthetic_images(B, channels=ch, seed=70 + i)).cuda())
+    assert models[2].w.middle_fusion and models[2].w.rpn_channels == 512
+    pipe = FramePairPipeline(models, "probEn", "v-avg")
+    dets, fused = pipe(frames, [(512, 640)] * B, (800, 1000))
+    torch.cuda.synchronize()
+    assert fused["stride"] == 300 and all(int(d["counts"].min()) > 0 for d in dets)
+    j1 = [LF.predictions_to_j1([f"im{i}.jpeg" for i in range(B)], list(range(B)), [o["instances"] for o in m.to_instances(d)])
+          for m, d in zip(models, dets)]
+    host = LF.late_fusion(j1, ["probEn", "v-avg"])
+    cnt, off = fused["counts"].cpu().numpy(), fused["offsets"].cpu().numpy()
+    for i in range(B):
+        b, s, c = host[i]
+        sl = slice(off[i], off[i] + cnt[i])
+        assert cnt[i] == len(s) and cnt[i] > 0
+        np.testing.assert_array_equal(fused["classes"][sl].cpu().numpy(), c.numpy())
+        np.testing.assert_allclose(fused["scores"][sl].cpu().numpy(), s.numpy(), rtol=1e-6, equal_nan=True)
+        np.testing.assert_allclose(fused["boxes"][sl].cpu().numpy(), np.asarray(b), rtol=1e-9, atol=1e-9, equal_nan=True)
+    rows = LF.fused_rows_device(fused, list(range(100, 100 + B))).cpu().numpy()
+    assert rows.shape[1] == 7 and len(rows) <= int(cnt.sum()) and set(rows[:, 6].astype(int)) <= {0, 1, 2}
+    assert np.all(rows[:, 3] > 0) and np.all(rows[:, 4] > 0) and np.all((rows[:, 5] > 0) & (rows[:, 5] <= 1))
