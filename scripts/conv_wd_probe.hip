@@ -193,7 +193,7 @@ void run_1x1(const char* name, pe::ConvWdArgs a, const std::vector<_Float16>& hi
 void probe_1x1() {
     struct S { int N, H, W, Cin, Cout, stride, res_mode, relu; const char* what; };
     const S shapes[] = {{3, 10, 12, 128, 256, 1, 1, 1, "tiny (tail + res)"},
-                        {32, 50, 64, 256, 1024, 1, 1, 1, "res4 conv3 + residual"}, {32, 50, 64, 1024, 256, 1, 0, 1, "res4 conv1"},
+                        {32, 50, 64, 256, 1024, 1, 1, 1, "res4 conv3 + residual"}, {32, 50, 64, 256, 1024, 1, 0, 1, "res4 conv3 WITHOUT residual"}, {32, 50, 64, 1024, 256, 1, 0, 1, "res4 conv1"},
                         {32, 200, 256, 64, 256, 1, 1, 1, "res2 conv3 + residual"}, {32, 100, 128, 128, 512, 1, 1, 1, "res3 conv3 + residual"},
                         {32, 100, 128, 512, 256, 1, 2, 0, "fpn lateral3 + top-down"}, {32, 100, 128, 512, 1024, 2, 0, 0, "res4 shortcut (stride 2)"},
                         {32, 25, 32, 2048, 512, 1, 0, 1, "res5 conv1"}, {32000, 1, 1, 1024, 1024, 1, 0, 1, "fc2"}, {32000, 1, 1, 12544, 1024, 1, 0, 1, "fc1"},

@@ -12,8 +12,18 @@ csv.field_size_limit(1 << 30)
 
 
 def short(name):
-    name = name.split("(")[0] if not name.startswith("void ") else name[5:].split("(")[0]
-    return name[-70:]
+    name = name.replace("(anonymous namespace)::", "")
+    name = name[5:] if name.startswith("void ") else name
+    depth, out = 0, []
+    for ch in name:           # cut the argument list: the first "(" outside template brackets
+        if ch == "<":
+            depth += 1
+        elif ch == ">":
+            depth -= 1
+        elif ch == "(" and depth == 0:
+            break
+        out.append(ch)
+    return "".join(out)[-70:]
 
 
 def main():
