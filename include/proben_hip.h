@@ -135,6 +135,14 @@ int pe_conv_wd_supported(int32_t kernel, int32_t stride, int32_t H, int32_t W, i
 int pe_conv_wd_pack_weights(const void* weight, void* packed, int32_t Cout, int32_t Cin, int32_t kernel, void* stream);
 int pe_conv3x3_wd_f16(const void* input, const void* packed_weight, const float* bias, void* output, int32_t N,
                       int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t relu, int32_t out_stride, void* stream);
+/* StandardRPNHead.forward for one level in ONE launch (proposal_generator/rpn.py:74-85): t = relu(conv3x3(x)) with 256
+ * output channels never leaves the chip; head_out[m][0..15] = head_bias16 + head_weight[rows <= 16][256] * t[m]  (fp32 rows of
+ * 16: 3 objectness logits, 12 anchor deltas, 1 pad - the layout pe_rpn_select_topk reads).  head_weight is packed once with
+ * pe_conv_wd_pack_head ([rows][256] fp16 in, 16 KiB out); geometry rule of pe_conv_wd_supported with Cout = 256. */
+int pe_conv_wd_pack_head(const void* head_weight, void* packed, int32_t rows, int32_t C, void* stream);
+int pe_conv3x3_wd_rpn_head_f16(const void* input, const void* packed_weight, const float* bias, const void* packed_head,
+                               const float* head_bias16, float* head_out, int32_t N, int32_t H, int32_t W, int32_t Cin,
+                               void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Front-end layout kernels.

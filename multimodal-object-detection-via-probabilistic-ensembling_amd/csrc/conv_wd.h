@@ -42,6 +42,10 @@ struct ConvWdArgs {
     int out_stride;  // halfs between output pixels
     int seg, nseg;   // image-row segment length of a block tile and segments per tile
     int tiles_m, tiles_n;
+    // fused RPN head (HEAD builds): out[m][0..15] = head_b + head_w[16 x Cout] * relu(conv3x3(in))[m]
+    const _Float16* head_w;   // packed by pack_head_kernel
+    const float* head_b;      // [16]
+    float* head_out;          // [M, 16] fp32
     // 1x1 lab kernel only (scripts/lab/conv_wd_1x1.h)
     int stride, Ho, Wo;          // output grid (stride 1 | 2)
     int res_mode, resH, resW;    // 0 none, 1 residual has the output's shape, 2 residual [N,resH,resW,Cout] read at (oh/2, ow/2)
@@ -75,7 +79,11 @@ __host__ __device__ inline int k3x3_of_kseq(int kseq, int Cin, int e) {
 // ------------------------------------------------------------------------------------------------------
 // ABL (measurement builds only, results wrong): 1 = no weight loads in the loop, 2 = no LDS fragment reads in the loop,
 // 4 = no slab traffic and no barrier in the loop
-template <int WM, int WN, int TPX, int DEPTH, int ABL = 0>
+// HEAD: the StandardRPNHead form (proposal_generator/rpn.py:74-85): the ReLU'd 3x3 output t never goes to memory; each wave
+// multiplies its 64 channels of t - the accumulators, converted to fp16, ARE MFMA B fragments when the head weight's K order
+// is packed to match - with the 15 x 256 objectness / delta weights, the four partial [128 px x 16] sums are added through LDS
+// and only the fp32 head rows (64 B per pixel instead of 512 B of t, and no second launch that re-reads t) are stored.
+template <int WM, int WN, int TPX, int DEPTH, int ABL = 0, bool HEAD = false>
 __global__ __launch_bounds__(64 * WM * WN, (TPX <= 4 ? 2 : 1)) void conv3x3_wd_kernel(pe::ConvWdArgs a) {
     constexpr int THREADS = 64 * WM * WN;
     constexpr int BPX = WM * TPX * 32;                  // pixels per block tile
@@ -245,13 +253,57 @@ __global__ __launch_bounds__(64 * WM * WN, (TPX <= 4 ? 2 : 1)) void conv3x3_wd_k
     }
 
     // ---- epilogue: ReLU + fp16, 64 contiguous bytes per lane and pixel block ----
-    if (a.relu) {
+    if (a.relu || HEAD) {
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
             for (int i = 0; i < TPX; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[blk][i][r] = fmaxf(acc[blk][i][r], 0.f);
+    }
+    if constexpr (HEAD) {
+        static_assert(WM == 1 && WN == 4 && TPX == 4, "fused head: one 128-pixel x 256-channel tile per workgroup");
+        // head weight fragments of this wave: K-step j covers channels wn*64 + (lane>>5)*32 + j*8 .. +8
+        half8 hw[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) hw[j] = *reinterpret_cast<const half8*>(a.head_w + ((wn * 4 + j) * 64 + lane) * 8);
+        float* red = reinterpret_cast<float*>(smem);     // [4 waves][128 px][16] fp32 = 32 KiB over the (now idle) slab ring
+#pragma unroll
+        for (int i = 0; i < TPX; ++i) {
+            float16v hd;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) hd[r] = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                half8 bf;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bf[e] = (_Float16)acc[j >> 1][i][(j & 1) * 8 + e];
+                hd = __builtin_amdgcn_mfma_f32_32x32x16_f16(hw[j], bf, hd, 0, 0, 0);
+            }
+            // rows (= head outputs) held by this lane: 4h + (r & 3) + 8 (r >> 2): r 0..3 -> o = 4h + r, r 4..7 -> o = 8 + 4h + (r - 4)
+            float* dst = red + ((wn * 128 + i * 32 + (lane & 31)) * 16) + (lane >> 5) * 4;
+            *reinterpret_cast<float4*>(dst) = make_float4(hd[0], hd[1], hd[2], hd[3]);
+            *reinterpret_cast<float4*>(dst + 8) = make_float4(hd[4], hd[5], hd[6], hd[7]);
+        }
+        __syncthreads();
+        {
+            const int px = tid >> 1, q = tid & 1;
+            const int m = m0 + px;
+            float4 s0 = *reinterpret_cast<const float4*>(a.head_b + q * 8), s1 = *reinterpret_cast<const float4*>(a.head_b + q * 8 + 4);
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const float4 x0 = *reinterpret_cast<const float4*>(red + (w * 128 + px) * 16 + q * 8);
+                const float4 x1 = *reinterpret_cast<const float4*>(red + (w * 128 + px) * 16 + q * 8 + 4);
+                s0.x += x0.x; s0.y += x0.y; s0.z += x0.z; s0.w += x0.w;
+                s1.x += x1.x; s1.y += x1.y; s1.z += x1.z; s1.w += x1.w;
+            }
+            if (m < a.M) {
+                float* o = a.head_out + (size_t)m * 16 + q * 8;
+                *reinterpret_cast<float4*>(o) = s0;
+                *reinterpret_cast<float4*>(o + 4) = s1;
+            }
+        }
+        return;
     }
 #pragma unroll
     for (int i = 0; i < TPX; ++i) {
@@ -270,6 +322,21 @@ __global__ __launch_bounds__(64 * WM * WN, (TPX <= 4 ? 2 : 1)) void conv3x3_wd_k
     }
 }
 
+// head weights [rows <= 16][256] fp16 -> A fragments in the K order the accumulator layout dictates:
+// record (wn, j), lane l: row = l & 31 (rows >= `rows` are zero), 8 halfs = channels wn*64 + (l>>5)*32 + j*8 + e
+__global__ void pack_head_kernel(const _Float16* w, _Float16* out, int rows, int C) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;     // one thread per lane slot: 4 wn x 4 j x 64 lanes
+    if (idx >= 4 * 4 * 64) return;
+    const int lane = idx & 63, j = (idx >> 6) & 3, wn = idx >> 8;
+    const int row = lane & 31;
+    half8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int ch = wn * 64 + (lane >> 5) * 32 + j * 8 + e;
+        v[e] = row < rows ? w[(size_t)row * C + ch] : (_Float16)0.f;
+    }
+    *reinterpret_cast<half8*>(out + (size_t)idx * 8) = v;
+}
 
 // packing: [Cout][3][3][Cin] (or [Cout][K] for 1x1 with order = 0) -> fragment records
 __global__ void pack_weights_kernel(const _Float16* w, _Float16* out, int Cout, int K, int Cin, int WN, int is3x3) {
@@ -304,20 +371,21 @@ inline bool wd3x3_geometry(int W, int BPX, int* seg, int* nseg) {
     return true;
 }
 
-template <int WM, int WN, int TPX, int DEPTH, int ABL = 0>
+template <int WM, int WN, int TPX, int DEPTH, int ABL = 0, bool HEAD = false>
 int launch_conv3x3_wd(pe::ConvWdArgs a, hipStream_t st) {
     constexpr int BPX = WM * TPX * 32;
     if (!wd3x3_geometry(a.W, BPX, &a.seg, &a.nseg)) return PE_ERR_UNSUPPORTED;
     a.tiles_m = pe::ceil_div(a.M, BPX);
     a.tiles_n = a.Cout / (WN * 64);
-    const size_t lds = (size_t)3 * a.nseg * (a.seg + 2) * SLAB_ROW_B + (size_t)64 * WM * WN * 16;
+    size_t lds = (size_t)3 * a.nseg * (a.seg + 2) * SLAB_ROW_B + (size_t)64 * WM * WN * 16;
+    if (HEAD && lds < 32768) lds = 32768;   // the partial head sums reuse the slab ring
     static bool done = false;
     if (!done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wd_kernel<WM, WN, TPX, DEPTH, ABL>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wd_kernel<WM, WN, TPX, DEPTH, ABL, HEAD>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         done = true;
     }
-    hipLaunchKernelGGL((conv3x3_wd_kernel<WM, WN, TPX, DEPTH, ABL>), dim3(a.tiles_m * a.tiles_n), dim3(64 * WM * WN), lds, st, a);
+    hipLaunchKernelGGL((conv3x3_wd_kernel<WM, WN, TPX, DEPTH, ABL, HEAD>), dim3(a.tiles_m * a.tiles_n), dim3(64 * WM * WN), lds, st, a);
     return PE_OK;
 }
 

@@ -54,3 +54,36 @@ extern "C" int pe_conv3x3_wd_f16(const void* input, const void* packed_weight, c
     PE_CHECK_LAUNCH("pe_conv3x3_wd_f16");
     return PE_OK;
 }
+
+extern "C" int pe_conv_wd_pack_head(const void* head_weight, void* packed, int32_t rows, int32_t C, void* stream) {
+    PE_CHECK_ARG(head_weight && packed && rows >= 1 && rows <= 16 && C == 256,
+                 "pe_conv_wd_pack_head: needs rows <= 16 and 256 input channels (got %d, %d)", rows, C);
+    hipLaunchKernelGGL(wd::pack_head_kernel, dim3(4), dim3(256), 0, (hipStream_t)stream, (const _Float16*)head_weight,
+                       (_Float16*)packed, rows, C);
+    PE_CHECK_LAUNCH("pe_conv_wd_pack_head");
+    return PE_OK;
+}
+
+extern "C" int pe_conv3x3_wd_rpn_head_f16(const void* input, const void* packed_weight, const float* bias,
+                                          const void* packed_head, const float* head_bias16, float* head_out, int32_t N,
+                                          int32_t H, int32_t W, int32_t Cin, void* stream) {
+    PE_CHECK_ARG(input && packed_weight && bias && packed_head && head_bias16 && head_out, "pe_conv3x3_wd_rpn_head_f16: null pointer");
+    PE_CHECK_ARG(N > 0 && H > 0 && W > 0, "pe_conv3x3_wd_rpn_head_f16: bad dims");
+    if (!pe_conv_wd_supported(3, 1, H, W, Cin, 256)) {
+        pe::set_error("pe_conv3x3_wd_rpn_head_f16: geometry not supported (W %d, Cin %d): run the two convolutions", W, Cin);
+        return PE_ERR_UNSUPPORTED;
+    }
+    const long long M = (long long)N * H * W;
+    PE_CHECK_ARG(M * Cin * 2 < (1ll << 32) && M < (1ll << 31), "pe_conv3x3_wd_rpn_head_f16: input larger than 4 GiB");
+    pe::ConvWdArgs a{};
+    a.in = (const _Float16*)input; a.wpk = (const _Float16*)packed_weight; a.bias = bias; a.out = nullptr;
+    a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = 256; a.M = (int)M; a.relu = 1; a.out_stride = 256;
+    a.head_w = (const _Float16*)packed_head; a.head_b = head_bias16; a.head_out = head_out;
+    const int st = wd::launch_conv3x3_wd<1, 4, 4, 4, 0, true>(a, (hipStream_t)stream);
+    if (st != PE_OK) {
+        pe::set_error("pe_conv3x3_wd_rpn_head_f16: unsupported geometry");
+        return st;
+    }
+    PE_CHECK_LAUNCH("pe_conv3x3_wd_rpn_head_f16");
+    return PE_OK;
+}

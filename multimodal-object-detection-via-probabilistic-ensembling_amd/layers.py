@@ -194,9 +194,37 @@ def conv3x3_wd(x, packed, bias, cout, *, relu=False, out=None, out_stride=0):
     _lib.check(st, "pe_conv3x3_wd_f16")
     if PROFILE is not None:
         M = N * H * W
-        PROFILE.append({"variant": "conv3x3_wd_kernel<1, 4, 4, 4, 0>", "shape": f"N{N} {H}x{W} Cin{Cin} Cout{cout} k3 s1 res0 f320",
+        PROFILE.append({"variant": "conv3x3_wd_kernel<1, 4, 4, 4, 0, false>", "shape": f"N{N} {H}x{W} Cin{Cin} Cout{cout} k3 s1 res0 f320",
                         "flops": 2.0 * M * cout * 9 * Cin, "bytes": float(M * Cin * 2 + cout * 9 * Cin * 2 + M * cout * 2),
                         "replay": (lambda: conv3x3_wd(x, packed, bias, cout, relu=relu, out=out, out_stride=out_stride))})
+    return out
+
+
+def conv_wd_pack_head(weight2d):
+    """[rows <= 16, 256] fp16 head weight (objectness + anchor deltas) -> the fragment-ordered 16 KiB block of the fused RPN head."""
+    _lib.require_cuda(weight2d)
+    rows, C = weight2d.shape
+    assert weight2d.dtype == torch.float16 and weight2d.is_contiguous()
+    packed = torch.empty(4 * 4 * 64 * 8, dtype=torch.float16, device=weight2d.device)
+    _lib.check(_lib.lib().pe_conv_wd_pack_head(_lib.ptr(weight2d), _lib.ptr(packed), rows, C, _lib.stream()), "pe_conv_wd_pack_head")
+    return packed
+
+
+def conv3x3_wd_rpn_head(x, packed, bias, packed_head, head_bias16, out=None):
+    """StandardRPNHead for one level in one launch: relu(conv3x3(x)) (256 channels, never stored) -> 1x1 head ->
+    fp32 [N,H,W,16] (3 objectness logits, 12 deltas, 1 pad)."""
+    _lib.require_cuda(x, packed, bias, packed_head, head_bias16)
+    N, H, W, Cin = x.shape
+    if out is None:
+        out = torch.empty((N, H, W, 16), dtype=torch.float32, device=x.device)
+    st = _lib.lib().pe_conv3x3_wd_rpn_head_f16(_lib.ptr(x), _lib.ptr(packed), _lib.ptr(bias), _lib.ptr(packed_head), _lib.ptr(head_bias16),
+                                               _lib.ptr(out), N, H, W, Cin, _lib.stream())
+    _lib.check(st, "pe_conv3x3_wd_rpn_head_f16")
+    if PROFILE is not None:
+        M = N * H * W
+        PROFILE.append({"variant": "conv3x3_wd_kernel<1, 4, 4, 4, 0, true>", "shape": f"N{N} {H}x{W} Cin{Cin} Cout256+head k3 s1 res0 f321",
+                        "flops": 2.0 * M * 256 * 9 * Cin + 2.0 * M * 15 * 256, "bytes": float(M * Cin * 2 + 256 * 9 * Cin * 2 + M * 15 * 4),
+                        "replay": (lambda: conv3x3_wd_rpn_head(x, packed, bias, packed_head, head_bias16, out=out))})
     return out
 
 

@@ -219,7 +219,12 @@ class GeneralizedRCNN:
         hw, strides = [], [4, 8, 16, 32, 64]
         if heads is None:
             heads = []
+            fused = self.w.rpn_head_fused if self.use_wd else None
             for f in feats:
+                if fused is not None and L.conv_wd_supported(3, 1, f.shape[1], f.shape[2], f.shape[3], 256):
+                    # StandardRPNHead in one launch: the 256-channel ReLU'd map never goes to HBM
+                    heads.append(L.conv3x3_wd_rpn_head(f, self.w.wd["rpn.conv"], self.w.convs["rpn.conv"][1], fused[0], fused[1]))
+                    continue
                 t = self._conv(f, "rpn.conv", kernel=3, relu=True)
                 w, b = self.w.convs["rpn.head"]
                 heads.append(L.conv2d_nhwc(t, w, b, kernel=1, out_f32=True, cout=15, cout_store=15, out_stride=16))

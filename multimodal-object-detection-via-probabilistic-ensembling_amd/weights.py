@@ -114,6 +114,13 @@ class PackedDetector:
         for name, (w, b) in self.convs.items():
             if w.dim() == 4 and w.shape[1] == 3 and w.shape[2] == 3 and w.shape[3] % 64 == 0 and w.shape[0] % 256 == 0 and b is not None:
                 self.wd[name] = L.conv_wd_pack(w)
+        # fused StandardRPNHead (3x3 + ReLU + 1x1 in one launch) when the RPN is 256 wide
+        self.rpn_head_fused = None
+        hw, hb = self.convs["rpn.head"]
+        if "rpn.conv" in self.wd and self.convs["rpn.conv"][0].shape[0] == 256 and hw.shape[0] <= 16:
+            b16 = torch.zeros(16, dtype=torch.float32, device=self.device)
+            b16[: hb.shape[0]] = hb
+            self.rpn_head_fused = (L.conv_wd_pack_head(hw.reshape(hw.shape[0], -1).contiguous()), b16)
 
     def _pack_backbone(self, sd, prefix):
         dev = self.device

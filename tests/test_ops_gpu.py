@@ -166,6 +166,34 @@ def test_conv3x3_weights_direct_kernel(L, case):
     torch.testing.assert_close(outs[0].permute(0, 3, 1, 2).float(), ref, rtol=4e-3, atol=4e-3)
 
 
+@pytest.mark.parametrize("shape", [(2, 40, 64, 256), (1, 13, 128, 256), (3, 5, 32, 256), (2, 8, 256, 512)])
+def test_fused_rpn_head_matches_two_launch_path_and_torch(L, shape):
+    """StandardRPNHead (proposal_generator/rpn.py:74-85) in one launch == 3x3 + ReLU then the 15-column 1x1 (the fp16
+    rounding of t is the same; only the fp32 summation order over the four 64-channel slices differs) == torch fp32."""
+    N, H, W, Cin = shape
+    g = torch.Generator(device="cpu").manual_seed(31)
+    x = torch.randn(N, Cin, H, W, generator=g).cuda().half()
+    w3 = (torch.randn(256, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5).cuda().half()
+    b3 = torch.randn(256, generator=g).cuda()
+    wh = (torch.randn(15, 256, 1, 1, generator=g) / 16.0).cuda().half()
+    bh = torch.randn(15, generator=g).cuda()
+    t_ref = torch.nn.functional.conv2d(x.float(), w3.float(), b3, padding=1).relu()
+    ref = torch.nn.functional.conv2d(t_ref, wh.float(), bh).permute(0, 2, 3, 1)
+    pk = L.conv_wd_pack(w3.permute(0, 2, 3, 1).contiguous())
+    ph = L.conv_wd_pack_head(wh.reshape(15, 256).contiguous())
+    b16 = torch.zeros(16, device="cuda")
+    b16[:15] = bh
+    outs = [L.conv3x3_wd_rpn_head(nhwc(x), pk, b3, ph, b16) for _ in range(2)]
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1])
+    fused = outs[0]
+    assert fused.shape == (N, H, W, 16) and float(fused[..., 15].abs().max()) == 0.0
+    t = L.conv3x3_wd(nhwc(x), pk, b3, 256, relu=True)
+    two = L.conv2d_nhwc(t, wh.permute(0, 2, 3, 1).contiguous(), bh, kernel=1, out_f32=True, cout=15, cout_store=15, out_stride=16)
+    torch.testing.assert_close(fused[..., :15], two[..., :15], rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(fused[..., :15], ref, rtol=4e-3, atol=4e-3)
+
+
 def test_conv3x3_weights_direct_matches_lds_kernel_and_rejects_other_geometry(L):
     """Same fp16 inputs through the weights-direct and the LDS-DMA 3x3 kernels: both accumulate in fp32 over the same
     products, so they agree to fp32 summation-order noise; unsupported widths are refused loudly."""
