@@ -139,6 +139,15 @@ int pe_conv3x3_wd_f16(const void* input, const void* packed_weight, const float*
  * output channels never leaves the chip; head_out[m][0..15] = head_bias16 + head_weight[rows <= 16][256] * t[m]  (fp32 rows of
  * 16: 3 objectness logits, 12 anchor deltas, 1 pad - the layout pe_rpn_select_topk reads).  head_weight is packed once with
  * pe_conv_wd_pack_head ([rows][256] fp16 in, 16 KiB out); geometry rule of pe_conv_wd_supported with Cout = 256. */
+/* The second half of BottleneckBlock.forward in ONE launch (modeling/backbone/resnet.py:207-221): conv2 3x3 (Cin -> 256,
+ * folded BN) + ReLU -> conv3 1x1 (256 -> tail_cout, folded BN) + shortcut + ReLU.  The 256-channel intermediate stays on the
+ * chip (LDS) and the stand-alone, latency-bound 1x1 launch disappears.  tail weight [tail_cout][256] fp16 is packed once with
+ * pe_conv_wd_pack_tail (same size out); residual (optional) and output are [N,H,W,tail_cout] fp16; tail_cout % 256 == 0;
+ * geometry rule of pe_conv_wd_supported with Cout = 256. */
+int pe_conv_wd_pack_tail(const void* weight, void* packed, int32_t tail_cout, int32_t C, void* stream);
+int pe_bottleneck_tail_wd_f16(const void* input, const void* packed_weight3x3, const float* bias3x3, const void* packed_tail,
+                              const float* tail_bias, const void* residual, void* output, int32_t N, int32_t H, int32_t W,
+                              int32_t Cin, int32_t tail_cout, void* stream);
 int pe_conv_wd_pack_head(const void* head_weight, void* packed, int32_t rows, int32_t C, void* stream);
 int pe_conv3x3_wd_rpn_head_f16(const void* input, const void* packed_weight, const float* bias, const void* packed_head,
                                const float* head_bias16, float* head_out, int32_t N, int32_t H, int32_t W, int32_t Cin,

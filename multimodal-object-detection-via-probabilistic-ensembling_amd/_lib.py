@@ -22,6 +22,8 @@ SIGNATURES = {
     "pe_conv_wd_supported": [c_int] * 6,
     "pe_conv_wd_pack_weights": [c_void_p] * 2 + [c_int] * 3 + [c_void_p],
     "pe_conv3x3_wd_f16": [c_void_p] * 4 + [c_int] * 7 + [c_void_p],
+    "pe_conv_wd_pack_tail": [c_void_p] * 2 + [c_int] * 2 + [c_void_p],
+    "pe_bottleneck_tail_wd_f16": [c_void_p] * 7 + [c_int] * 5 + [c_void_p],
     "pe_conv_wd_pack_head": [c_void_p] * 2 + [c_int] * 2 + [c_void_p],
     "pe_conv3x3_wd_rpn_head_f16": [c_void_p] * 6 + [c_int] * 4 + [c_void_p],
     "pe_preprocess_pack": [c_void_p] + [c_int] * 11 + [c_void_p] * 4,

@@ -46,6 +46,12 @@ struct ConvWdArgs {
     const _Float16* head_w;   // packed by pack_head_kernel
     const float* head_b;      // [16]
     float* head_out;          // [M, 16] fp32
+    // fused bottleneck tail (TAIL builds): tail_out = relu(tail_b + tail_w[tail_cout x 256] * relu(conv3x3(in)) + tail_res)
+    const _Float16* tail_w;   // packed by pack_tail_kernel
+    const float* tail_b;      // [tail_cout]
+    const _Float16* tail_res; // [M, tail_cout] fp16 or null
+    _Float16* tail_out;       // [M, tail_cout] fp16
+    int tail_cout;            // multiple of 256
     // 1x1 lab kernel only (scripts/lab/conv_wd_1x1.h)
     int stride, Ho, Wo;          // output grid (stride 1 | 2)
     int res_mode, resH, resW;    // 0 none, 1 residual has the output's shape, 2 residual [N,resH,resW,Cout] read at (oh/2, ow/2)
@@ -83,7 +89,12 @@ __host__ __device__ inline int k3x3_of_kseq(int kseq, int Cin, int e) {
 // multiplies its 64 channels of t - the accumulators, converted to fp16, ARE MFMA B fragments when the head weight's K order
 // is packed to match - with the 15 x 256 objectness / delta weights, the four partial [128 px x 16] sums are added through LDS
 // and only the fp32 head rows (64 B per pixel instead of 512 B of t, and no second launch that re-reads t) are stored.
-template <int WM, int WN, int TPX, int DEPTH, int ABL = 0, bool HEAD = false>
+// HEAD == 2 ("tail"): the second half of a BottleneckBlock (backbone/resnet.py:205-221) in the same launch: t = relu(conv2(x))
+// (128 px x 256 channels per workgroup) is written as fp16 into the idle slab ring, then every wave computes 256 of the
+// tail_cout outputs of conv3 in chunks of 64 - t fragments from LDS, conv3 weights L2 -> VGPR in fragment order, no barrier in
+// the whole phase -, adds the shortcut (one channel quarter per 4 K-steps, requested 3 K-steps ahead, 16 registers live) and ReLU, and stores.
+// Neither t nor a second launch's re-read of it touches HBM, and the latency-bound 1x1 kernel is gone from the block.
+template <int WM, int WN, int TPX, int DEPTH, int ABL = 0, int HEAD = 0>
 __global__ __launch_bounds__(64 * WM * WN, (TPX <= 4 ? 2 : 1)) void conv3x3_wd_kernel(pe::ConvWdArgs a) {
     constexpr int THREADS = 64 * WM * WN;
     constexpr int BPX = WM * TPX * 32;                  // pixels per block tile
@@ -261,7 +272,7 @@ __global__ __launch_bounds__(64 * WM * WN, (TPX <= 4 ? 2 : 1)) void conv3x3_wd_k
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[blk][i][r] = fmaxf(acc[blk][i][r], 0.f);
     }
-    if constexpr (HEAD) {
+    if constexpr (HEAD == 1) {
         static_assert(WM == 1 && WN == 4 && TPX == 4, "fused head: one 128-pixel x 256-channel tile per workgroup");
         // head weight fragments of this wave: K-step j covers channels wn*64 + (lane>>5)*32 + j*8 .. +8
         half8 hw[4];
@@ -305,6 +316,129 @@ __global__ __launch_bounds__(64 * WM * WN, (TPX <= 4 ? 2 : 1)) void conv3x3_wd_k
         }
         return;
     }
+    if constexpr (HEAD == 2) {
+        static_assert(WM == 1 && WN == 4 && TPX == 4 && DEPTH == 4, "fused tail: one 128-pixel x 256-channel tile per workgroup");
+        constexpr int TROW = 528;                       // 256 halfs + 16 B pad: rows r .. r+15 hit 16 distinct bank groups
+        // ---- t -> LDS (the slab ring is idle: every wave passed the loop's last barrier) ----
+#pragma unroll
+        for (int i = 0; i < TPX; ++i) {
+            unsigned char* dst = smem + (i * 32 + (lane & 31)) * TROW + (wn * 64 + (lane >> 5) * 32) * 2;
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    half8 v;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (_Float16)acc[blk][i][hh * 8 + e];
+                    *reinterpret_cast<half8*>(dst + (blk * 16 + hh * 8) * 2) = v;
+                }
+        }
+        __syncthreads();
+        const int NCH = a.tail_cout / 256;               // 64-output chunks per wave
+        const int NS = NCH * 16;                         // K-steps of the tail phase (K = 256)
+        const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.tail_w), 0, a.tail_cout * 256 * 2, 0x00020000);
+        const int t_base = wn * NCH * 16 * 2048;
+        auto t_load = [&](int slot, int step) {
+            const int so = t_base + (step < NS ? step : NS - 1) * 2048;
+            wf[slot][0] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rt, lane * 16, so, 0));
+            wf[slot][1] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rt, lane * 16 + 1024, so, 0));
+        };
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) t_load(d, d);
+        int tb[TPX];
+#pragma unroll
+        for (int i = 0; i < TPX; ++i) tb[i] = (i * 32 + (lane & 31)) * TROW + (lane >> 5) * 16;
+#pragma unroll
+        for (int i = 0; i < TPX; ++i) pf[0][i] = *reinterpret_cast<const half8*>(smem + tb[i]);
+        const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.tail_res ? a.tail_res : a.in), 0,
+                                                                            a.tail_res ? a.M * a.tail_cout * 2 : 0, 0x00020000);
+        unsigned rbase[TPX];                              // byte offset of this lane's 64 residual bytes for chunk 0, or out of range
+#pragma unroll
+        for (int i = 0; i < TPX; ++i) {
+            const int m = m0 + i * 32 + (lane & 31);
+            rbase[i] = (a.tail_res && m < a.M) ? (unsigned)(((size_t)m * a.tail_cout + wn * (NCH * 64) + (lane >> 5) * 32) * 2) : 0xFFFFFFF0u;
+        }
+        for (int c = 0; c < NCH; ++c) {
+            const int ob = wn * (NCH * 64) + c * 64 + (lane >> 5) * 32;    // this lane's 32 consecutive outputs of the chunk
+            {
+                const float* bp = a.tail_b + ob;
+#pragma unroll
+                for (int blk = 0; blk < 2; ++blk) {
+                    float16v b;
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        const float4 v = *reinterpret_cast<const float4*>(bp + blk * 16 + r4 * 4);
+                        b[r4 * 4 + 0] = v.x; b[r4 * 4 + 1] = v.y; b[r4 * 4 + 2] = v.z; b[r4 * 4 + 3] = v.w;
+                    }
+#pragma unroll
+                    for (int i = 0; i < TPX; ++i) acc[blk][i] = b;
+                }
+            }
+            half8 rv[4];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {
+                // shortcut, one CHANNEL quarter (8 of the lane's 32 outputs) of all four pixel blocks per 4 K-steps: requested at
+                // ks % 4 == 0, added 3 K-steps later.  Splitting by channel - not by pixel block - keeps the fp32 summation order
+                // of an output independent of where its pixel sits in the tile (results do not depend on the batch composition).
+                if ((ks & 3) == 0) {
+#pragma unroll
+                    for (int i = 0; i < TPX; ++i)
+                        rv[i] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(
+                            rr, rbase[i] == 0xFFFFFFF0u ? rbase[i] : rbase[i] + (unsigned)(c * 128 + (ks >> 2) * 16), 0, 0));
+                }
+                if (ks + 1 < 16) {
+#pragma unroll
+                    for (int i = 0; i < TPX; ++i) pf[(ks + 1) & 1][i] = *reinterpret_cast<const half8*>(smem + tb[i] + (ks + 1) * 32);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < TPX; ++i) pf[(ks + 1) & 1][i] = *reinterpret_cast<const half8*>(smem + tb[i]);
+                }
+#pragma unroll
+                for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                    for (int i = 0; i < TPX; ++i)
+                        acc[blk][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks & 3][blk], pf[ks & 1][i], acc[blk][i], 0, 0, 0);
+                t_load(ks & 3, c * 16 + ks + DEPTH);
+#pragma unroll
+                for (int i = 0; i < TPX; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, TPX - 2, 0);
+                if ((ks & 3) == 0) __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if ((ks & 3) == 3) {
+                    const int q = ks >> 2;
+#pragma unroll
+                    for (int i = 0; i < TPX; ++i)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) acc[q >> 1][i][(q & 1) * 8 + e] += (float)rv[i][e];
+                }
+            }
+            // chunk epilogue: ReLU, fp16, 64 contiguous bytes per lane and pixel block
+#pragma unroll
+            for (int i = 0; i < TPX; ++i) {
+                const int m = m0 + i * 32 + (lane & 31);
+                if (m >= a.M) continue;
+                _Float16* o = a.tail_out + (size_t)m * a.tail_cout + ob;
+#pragma unroll
+                for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {
+                        half8 v;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = (_Float16)fmaxf(acc[blk][i][hh * 8 + e], 0.f);
+                        *reinterpret_cast<half8*>(o + blk * 16 + hh * 8) = v;
+                    }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TPX; ++i) {
         const int m = m0 + (wm * TPX + i) * 32 + (lane & 31);
@@ -320,6 +454,24 @@ __global__ __launch_bounds__(64 * WM * WN, (TPX <= 4 ? 2 : 1)) void conv3x3_wd_k
                 *reinterpret_cast<half8*>(o + blk * 16 + hh * 8) = v;
             }
     }
+}
+
+// conv3 weights [tail_cout][256] fp16 -> fragment records in the tail phase's stream order:
+// record (wn, c, ks, blk), lane l: output = wn*(NCH*64) + c*64 + cout_perm(blk, l & 31), 8 halfs = k ks*16 + (l>>5)*8 + e
+__global__ void pack_tail_kernel(const _Float16* w, _Float16* out, int tail_cout) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;     // one thread per lane slot
+    const int NCH = tail_cout / 256;
+    if (idx >= 4 * NCH * 16 * 2 * 64) return;
+    const int lane = idx & 63;
+    int rec = idx >> 6;
+    const int blk = rec & 1; rec >>= 1;
+    const int ks = rec & 15; rec >>= 4;
+    const int c = rec % NCH, wn = rec / NCH;
+    const int o = wn * (NCH * 64) + c * 64 + cout_perm(blk, lane & 31);
+    half8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = w[(size_t)o * 256 + ks * 16 + (lane >> 5) * 8 + e];
+    *reinterpret_cast<half8*>(out + (size_t)idx * 8) = v;
 }
 
 // head weights [rows <= 16][256] fp16 -> A fragments in the K order the accumulator layout dictates:
@@ -371,14 +523,15 @@ inline bool wd3x3_geometry(int W, int BPX, int* seg, int* nseg) {
     return true;
 }
 
-template <int WM, int WN, int TPX, int DEPTH, int ABL = 0, bool HEAD = false>
+template <int WM, int WN, int TPX, int DEPTH, int ABL = 0, int HEAD = 0>
 int launch_conv3x3_wd(pe::ConvWdArgs a, hipStream_t st) {
     constexpr int BPX = WM * TPX * 32;
     if (!wd3x3_geometry(a.W, BPX, &a.seg, &a.nseg)) return PE_ERR_UNSUPPORTED;
     a.tiles_m = pe::ceil_div(a.M, BPX);
     a.tiles_n = a.Cout / (WN * 64);
     size_t lds = (size_t)3 * a.nseg * (a.seg + 2) * SLAB_ROW_B + (size_t)64 * WM * WN * 16;
-    if (HEAD && lds < 32768) lds = 32768;   // the partial head sums reuse the slab ring
+    if (HEAD == 1 && lds < 32768) lds = 32768;        // the partial head sums reuse the slab ring
+    if (HEAD == 2 && lds < 128 * 528) lds = 128 * 528;  // so does the fp16 copy of t
     static bool done = false;
     if (!done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wd_kernel<WM, WN, TPX, DEPTH, ABL, HEAD>),

@@ -79,11 +79,46 @@ extern "C" int pe_conv3x3_wd_rpn_head_f16(const void* input, const void* packed_
     a.in = (const _Float16*)input; a.wpk = (const _Float16*)packed_weight; a.bias = bias; a.out = nullptr;
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = 256; a.M = (int)M; a.relu = 1; a.out_stride = 256;
     a.head_w = (const _Float16*)packed_head; a.head_b = head_bias16; a.head_out = head_out;
-    const int st = wd::launch_conv3x3_wd<1, 4, 4, 4, 0, true>(a, (hipStream_t)stream);
+    const int st = wd::launch_conv3x3_wd<1, 4, 4, 4, 0, 1>(a, (hipStream_t)stream);
     if (st != PE_OK) {
         pe::set_error("pe_conv3x3_wd_rpn_head_f16: unsupported geometry");
         return st;
     }
     PE_CHECK_LAUNCH("pe_conv3x3_wd_rpn_head_f16");
+    return PE_OK;
+}
+
+extern "C" int pe_conv_wd_pack_tail(const void* weight, void* packed, int32_t tail_cout, int32_t C, void* stream) {
+    PE_CHECK_ARG(weight && packed && C == 256 && tail_cout > 0 && tail_cout % 256 == 0,
+                 "pe_conv_wd_pack_tail: needs 256 input channels and tail_cout %% 256 == 0 (got %d, %d)", C, tail_cout);
+    const int total = tail_cout * 256 / 8;
+    hipLaunchKernelGGL(wd::pack_tail_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const _Float16*)weight,
+                       (_Float16*)packed, tail_cout);
+    PE_CHECK_LAUNCH("pe_conv_wd_pack_tail");
+    return PE_OK;
+}
+
+extern "C" int pe_bottleneck_tail_wd_f16(const void* input, const void* packed_weight3x3, const float* bias3x3,
+                                         const void* packed_tail, const float* tail_bias, const void* residual, void* output,
+                                         int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t tail_cout, void* stream) {
+    PE_CHECK_ARG(input && packed_weight3x3 && bias3x3 && packed_tail && tail_bias && output, "pe_bottleneck_tail_wd_f16: null pointer");
+    PE_CHECK_ARG(N > 0 && H > 0 && W > 0 && tail_cout > 0 && tail_cout % 256 == 0, "pe_bottleneck_tail_wd_f16: bad dims");
+    if (!pe_conv_wd_supported(3, 1, H, W, Cin, 256)) {
+        pe::set_error("pe_bottleneck_tail_wd_f16: geometry not supported (W %d, Cin %d): run the two convolutions", W, Cin);
+        return PE_ERR_UNSUPPORTED;
+    }
+    const long long M = (long long)N * H * W;
+    PE_CHECK_ARG(M * tail_cout * 2 < (1ll << 32) && M < (1ll << 31), "pe_bottleneck_tail_wd_f16: tensors larger than 4 GiB");
+    pe::ConvWdArgs a{};
+    a.in = (const _Float16*)input; a.wpk = (const _Float16*)packed_weight3x3; a.bias = bias3x3; a.out = nullptr;
+    a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = 256; a.M = (int)M; a.relu = 1; a.out_stride = 256;
+    a.tail_w = (const _Float16*)packed_tail; a.tail_b = tail_bias; a.tail_res = (const _Float16*)residual;
+    a.tail_out = (_Float16*)output; a.tail_cout = tail_cout;
+    const int st = wd::launch_conv3x3_wd<1, 4, 4, 4, 0, 2>(a, (hipStream_t)stream);
+    if (st != PE_OK) {
+        pe::set_error("pe_bottleneck_tail_wd_f16: unsupported geometry");
+        return st;
+    }
+    PE_CHECK_LAUNCH("pe_bottleneck_tail_wd_f16");
     return PE_OK;
 }

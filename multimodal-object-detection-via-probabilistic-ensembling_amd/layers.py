@@ -194,9 +194,40 @@ def conv3x3_wd(x, packed, bias, cout, *, relu=False, out=None, out_stride=0):
     _lib.check(st, "pe_conv3x3_wd_f16")
     if PROFILE is not None:
         M = N * H * W
-        PROFILE.append({"variant": "conv3x3_wd_kernel<1, 4, 4, 4, 0, false>", "shape": f"N{N} {H}x{W} Cin{Cin} Cout{cout} k3 s1 res0 f320",
+        PROFILE.append({"variant": "conv3x3_wd_kernel<1, 4, 4, 4, 0, 0>", "shape": f"N{N} {H}x{W} Cin{Cin} Cout{cout} k3 s1 res0 f320",
                         "flops": 2.0 * M * cout * 9 * Cin, "bytes": float(M * Cin * 2 + cout * 9 * Cin * 2 + M * cout * 2),
                         "replay": (lambda: conv3x3_wd(x, packed, bias, cout, relu=relu, out=out, out_stride=out_stride))})
+    return out
+
+
+def conv_wd_pack_tail(weight2d):
+    """conv3 weight [tail_cout, 256] fp16 (BN folded) -> fragment records in the fused bottleneck tail's stream order."""
+    _lib.require_cuda(weight2d)
+    cout, C = weight2d.shape
+    assert weight2d.dtype == torch.float16 and weight2d.is_contiguous()
+    packed = torch.empty(cout * C, dtype=torch.float16, device=weight2d.device)
+    _lib.check(_lib.lib().pe_conv_wd_pack_tail(_lib.ptr(weight2d), _lib.ptr(packed), cout, C, _lib.stream()), "pe_conv_wd_pack_tail")
+    return packed
+
+
+def bottleneck_tail_wd(x, packed3x3, bias3x3, packed_tail, tail_bias, residual, tail_cout, out=None):
+    """relu(conv3(relu(conv2(x))) + residual) of a BottleneckBlock in one launch.  x [N,H,W,Cin] fp16 (conv1's output),
+    conv2: Cin -> 256, conv3: 256 -> tail_cout; residual [N,H,W,tail_cout] fp16 or None.  Returns [N,H,W,tail_cout] fp16."""
+    _lib.require_cuda(x, packed3x3, bias3x3, packed_tail, tail_bias)
+    N, H, W, Cin = x.shape
+    if out is None:
+        out = torch.empty((N, H, W, tail_cout), dtype=torch.float16, device=x.device)
+    if residual is not None:
+        assert residual.is_contiguous() and tuple(residual.shape) == (N, H, W, tail_cout)
+    st = _lib.lib().pe_bottleneck_tail_wd_f16(_lib.ptr(x), _lib.ptr(packed3x3), _lib.ptr(bias3x3), _lib.ptr(packed_tail), _lib.ptr(tail_bias),
+                                              _lib.ptr(residual), _lib.ptr(out), N, H, W, Cin, int(tail_cout), _lib.stream())
+    _lib.check(st, "pe_bottleneck_tail_wd_f16")
+    if PROFILE is not None:
+        M = N * H * W
+        PROFILE.append({"variant": "conv3x3_wd_kernel<1, 4, 4, 4, 0, 2>", "shape": f"N{N} {H}x{W} Cin{Cin} Cout256->{tail_cout} k3+k1 s1 res{int(residual is not None)} f320",
+                        "flops": 2.0 * M * 256 * 9 * Cin + 2.0 * M * tail_cout * 256,
+                        "bytes": float(M * Cin * 2 + 256 * 9 * Cin * 2 + tail_cout * 256 * 2 + M * tail_cout * 2 * (2 if residual is not None else 1)),
+                        "replay": (lambda: bottleneck_tail_wd(x, packed3x3, bias3x3, packed_tail, tail_bias, residual, tail_cout, out=out))})
     return out
 
 
@@ -222,7 +253,7 @@ def conv3x3_wd_rpn_head(x, packed, bias, packed_head, head_bias16, out=None):
     _lib.check(st, "pe_conv3x3_wd_rpn_head_f16")
     if PROFILE is not None:
         M = N * H * W
-        PROFILE.append({"variant": "conv3x3_wd_kernel<1, 4, 4, 4, 0, true>", "shape": f"N{N} {H}x{W} Cin{Cin} Cout256+head k3 s1 res0 f321",
+        PROFILE.append({"variant": "conv3x3_wd_kernel<1, 4, 4, 4, 0, 1>", "shape": f"N{N} {H}x{W} Cin{Cin} Cout256+head k3 s1 res0 f321",
                         "flops": 2.0 * M * 256 * 9 * Cin + 2.0 * M * 15 * 256, "bytes": float(M * Cin * 2 + 256 * 9 * Cin * 2 + M * 15 * 4),
                         "replay": (lambda: conv3x3_wd_rpn_head(x, packed, bias, packed_head, head_bias16, out=out))})
     return out

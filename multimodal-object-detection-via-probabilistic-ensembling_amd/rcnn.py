@@ -79,6 +79,7 @@ class GeneralizedRCNN:
         self._reg_w = (ctypes.c_float * 4)(10.0, 10.0, 5.0, 5.0)
         self.training = False
         self.use_wd = True   # weights-direct 3x3 kernel where the geometry allows (A/B switch)
+        self.fuse_tails = True   # conv2 + conv3 of a bottleneck in one launch where conv2 is 256 wide (A/B switch)
 
     def eval(self):
         return self
@@ -118,6 +119,12 @@ class GeneralizedRCNN:
                 stride = 2 if (bi == 0 and si > 0) else 1
                 sc = self._conv(x, p + ".shortcut", kernel=1, stride=stride) if (p + ".shortcut") in self.w.convs else x
                 o = self._conv(x, p + ".conv1", kernel=1, stride=stride, relu=True)
+                tail = self.w.tails.get(p) if self.use_wd and self.fuse_tails else None
+                if tail is not None and L.conv_wd_supported(3, 1, o.shape[1], o.shape[2], o.shape[3], 256):
+                    # conv2 + ReLU + conv3 + shortcut + ReLU in one launch: the 256-channel intermediate stays on the chip
+                    x = L.bottleneck_tail_wd(o, self.w.wd[p + ".conv2"], self.w.convs[p + ".conv2"][1], tail[0], tail[1], sc,
+                                             self.w.convs[p + ".conv3"][0].shape[0])
+                    continue
                 o = self._conv(o, p + ".conv2", kernel=3, relu=True)
                 x = self._conv(o, p + ".conv3", kernel=1, relu=True, residual=sc, residual_mode=1)
             outs.append(x)

@@ -114,6 +114,13 @@ class PackedDetector:
         for name, (w, b) in self.convs.items():
             if w.dim() == 4 and w.shape[1] == 3 and w.shape[2] == 3 and w.shape[3] % 64 == 0 and w.shape[0] % 256 == 0 and b is not None:
                 self.wd[name] = L.conv_wd_pack(w)
+        # fused bottleneck tails (conv2 3x3 + ReLU + conv3 1x1 + shortcut + ReLU in one launch) where conv2 is 256 wide (res4)
+        self.tails = {}
+        for name in list(self.wd):
+            if name.endswith(".conv2") and self.convs[name][0].shape[0] == 256:
+                w3, b3 = self.convs[name[:-1] + "3"]
+                if w3.shape[3] == 256 and w3.shape[0] % 256 == 0:
+                    self.tails[name[: -len(".conv2")]] = (L.conv_wd_pack_tail(w3.reshape(w3.shape[0], 256).contiguous()), b3)
         # fused StandardRPNHead (3x3 + ReLU + 1x1 in one launch) when the RPN is 256 wide
         self.rpn_head_fused = None
         hw, hb = self.convs["rpn.head"]

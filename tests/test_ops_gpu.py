@@ -194,6 +194,36 @@ def test_fused_rpn_head_matches_two_launch_path_and_torch(L, shape):
     torch.testing.assert_close(fused[..., :15], ref, rtol=4e-3, atol=4e-3)
 
 
+@pytest.mark.parametrize("shape", [(2, 50, 64, 256, 1024, True), (3, 5, 32, 256, 1024, True), (1, 9, 128, 128, 512, False), (2, 6, 256, 256, 256, True)])
+def test_fused_bottleneck_tail_matches_two_launch_path_and_torch(L, shape):
+    """BottleneckBlock's second half (backbone/resnet.py:207-221) in one launch == conv2 (weights-direct 3x3) + conv3 (LDS-DMA
+    1x1 with residual) as two launches == torch fp32; ragged M (480 pixels), no-residual form, run twice (race screen: the
+    fp16 copy of t reuses the slab ring after the loop's last barrier)."""
+    N, H, W, Cin, CoutT, with_res = shape
+    g = torch.Generator(device="cpu").manual_seed(37)
+    x = torch.randn(N, Cin, H, W, generator=g).cuda().half().relu()
+    w2 = (torch.randn(256, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5).cuda().half()
+    b2 = torch.randn(256, generator=g).cuda()
+    w3 = (torch.randn(CoutT, 256, 1, 1, generator=g) / 16.0).cuda().half()
+    b3 = torch.randn(CoutT, generator=g).cuda()
+    res = torch.randn(N, CoutT, H, W, generator=g).cuda().half() if with_res else None
+    t_ref = torch.nn.functional.conv2d(x.float(), w2.float(), b2, padding=1).relu()
+    ref = torch.nn.functional.conv2d(t_ref, w3.float(), b3)
+    if with_res:
+        ref = ref + res.float()
+    ref = ref.relu().permute(0, 2, 3, 1)
+    p2 = L.conv_wd_pack(w2.permute(0, 2, 3, 1).contiguous())
+    p3 = L.conv_wd_pack_tail(w3.reshape(CoutT, 256).contiguous())
+    r = nhwc(res) if with_res else None
+    outs = [L.bottleneck_tail_wd(nhwc(x), p2, b2, p3, b3, r, CoutT) for _ in range(2)]
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1])
+    t = L.conv3x3_wd(nhwc(x), p2, b2, 256, relu=True)
+    two = L.conv2d_nhwc(t, w3.permute(0, 2, 3, 1).contiguous(), b3, kernel=1, relu=True, residual=r, residual_mode=1 if with_res else 0)
+    torch.testing.assert_close(outs[0].float(), two.float(), rtol=2e-3, atol=2e-3)
+    torch.testing.assert_close(outs[0].float(), ref, rtol=5e-3, atol=5e-3)
+
+
 def test_conv3x3_weights_direct_matches_lds_kernel_and_rejects_other_geometry(L):
     """Same fp16 inputs through the weights-direct and the LDS-DMA 3x3 kernels: both accumulate in fp32 over the same
     products, so they agree to fp32 summation-order noise; unsupported widths are refused loudly."""
