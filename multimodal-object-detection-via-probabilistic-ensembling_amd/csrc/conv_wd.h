@@ -343,8 +343,8 @@ __global__ __launch_bounds__(64 * WM * WN, (TPX <= 4 ? 2 : 1)) void conv3x3_wd_k
             wf[slot][0] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rt, lane * 16, so, 0));
             wf[slot][1] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rt, lane * 16 + 1024, so, 0));
         };
-#pragma unroll
-        for (int d = 0; d < DEPTH; ++d) t_load(d, d);
+        t_load(0, 0);     // conv3's weights are L2 resident: two K-steps of prefetch; the registers saved carry the shortcut pipeline
+        t_load(1, 1);
         int tb[TPX];
 #pragma unroll
         for (int i = 0; i < TPX; ++i) tb[i] = (i * 32 + (lane & 31)) * TROW + (lane >> 5) * 16;
@@ -358,6 +358,18 @@ __global__ __launch_bounds__(64 * WM * WN, (TPX <= 4 ? 2 : 1)) void conv3x3_wd_k
             const int m = m0 + i * 32 + (lane & 31);
             rbase[i] = (a.tail_res && m < a.M) ? (unsigned)(((size_t)m * a.tail_cout + wn * (NCH * 64) + (lane >> 5) * 32) * 2) : 0xFFFFFFF0u;
         }
+        // shortcut quarters (8 of the lane's 32 outputs, all four pixel blocks) run as a rolling two-deep pipeline across the
+        // chunks: global quarter g = 4 c + q is requested at K-step 4 g - 4 and added at 4 g + 3 (7 K-steps of HBM latency
+        // slack, two quarters = 32 registers in flight).  Splitting by channel - not by pixel block - keeps the fp32 summation
+        // order of an output independent of where its pixel sits in the tile (results do not depend on the batch composition).
+        half8 rv[2][TPX];
+        auto r_load = [&](int set, int g) {      // g < 4 * NCH, else a harmless out-of-range request
+#pragma unroll
+            for (int i = 0; i < TPX; ++i)
+                rv[set][i] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(
+                    rr, (rbase[i] == 0xFFFFFFF0u || g >= 4 * NCH) ? 0xFFFFFFF0u : rbase[i] + (unsigned)((g >> 2) * 128 + (g & 3) * 16), 0, 0));
+        };
+        r_load(0, 0);
         for (int c = 0; c < NCH; ++c) {
             const int ob = wn * (NCH * 64) + c * 64 + (lane >> 5) * 32;    // this lane's 32 consecutive outputs of the chunk
             {
@@ -374,19 +386,10 @@ __global__ __launch_bounds__(64 * WM * WN, (TPX <= 4 ? 2 : 1)) void conv3x3_wd_k
                     for (int i = 0; i < TPX; ++i) acc[blk][i] = b;
                 }
             }
-            half8 rv[4];
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int ks = 0; ks < 16; ++ks) {
-                // shortcut, one CHANNEL quarter (8 of the lane's 32 outputs) of all four pixel blocks per 4 K-steps: requested at
-                // ks % 4 == 0, added 3 K-steps later.  Splitting by channel - not by pixel block - keeps the fp32 summation order
-                // of an output independent of where its pixel sits in the tile (results do not depend on the batch composition).
-                if ((ks & 3) == 0) {
-#pragma unroll
-                    for (int i = 0; i < TPX; ++i)
-                        rv[i] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(
-                            rr, rbase[i] == 0xFFFFFFF0u ? rbase[i] : rbase[i] + (unsigned)(c * 128 + (ks >> 2) * 16), 0, 0));
-                }
+                if ((ks & 3) == 0) r_load(((ks >> 2) + 1) & 1, c * 4 + (ks >> 2) + 1);   // the NEXT quarter (may belong to the next chunk)
                 if (ks + 1 < 16) {
 #pragma unroll
                     for (int i = 0; i < TPX; ++i) pf[(ks + 1) & 1][i] = *reinterpret_cast<const half8*>(smem + tb[i] + (ks + 1) * 32);
@@ -398,8 +401,8 @@ __global__ __launch_bounds__(64 * WM * WN, (TPX <= 4 ? 2 : 1)) void conv3x3_wd_k
                 for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
                     for (int i = 0; i < TPX; ++i)
-                        acc[blk][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks & 3][blk], pf[ks & 1][i], acc[blk][i], 0, 0, 0);
-                t_load(ks & 3, c * 16 + ks + DEPTH);
+                        acc[blk][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks & 1][blk], pf[ks & 1][i], acc[blk][i], 0, 0, 0);
+                t_load(ks & 1, c * 16 + ks + 2);
 #pragma unroll
                 for (int i = 0; i < TPX; ++i) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -417,7 +420,7 @@ __global__ __launch_bounds__(64 * WM * WN, (TPX <= 4 ? 2 : 1)) void conv3x3_wd_k
 #pragma unroll
                     for (int i = 0; i < TPX; ++i)
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) acc[q >> 1][i][(q & 1) * 8 + e] += (float)rv[i][e];
+                        for (int e = 0; e < 8; ++e) acc[q >> 1][i][(q & 1) * 8 + e] += (float)rv[q & 1][i][e];
                 }
             }
             // chunk epilogue: ReLU, fp16, 64 contiguous bytes per lane and pixel block
