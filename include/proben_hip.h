@@ -127,7 +127,7 @@ int pe_set_conv_tile256(int32_t mode);
  * backbone/resnet.py:205-221, backbone/fpn.py:127-137 and proposal_generator/rpn.py:74-85).
  * The weights are packed ONCE into MFMA-fragment order (pe_conv_wd_pack_weights) and streamed L2 -> VGPR; only the
  * pixels go through LDS.  Supported: stride 1 / pad 1, Cin % 64 == 0, Cout % 256 == 0, W % 32 == 0 with W | 128 or
- * 128 | W, input < 4 GiB; everything else -> pe_conv2d_nhwc_f16.  Epilogue: + bias (required) + ReLU, fp16 NHWC
+ * 128 | W, input < 2 GiB; everything else -> pe_conv2d_nhwc_f16.  Epilogue: + bias (required) + ReLU, fp16 NHWC
  * output with row stride out_stride (0 = Cout).
  * ------------------------------------------------------------------------------------------- */
 int pe_conv_wd_supported(int32_t kernel, int32_t stride, int32_t H, int32_t W, int32_t Cin, int32_t Cout);

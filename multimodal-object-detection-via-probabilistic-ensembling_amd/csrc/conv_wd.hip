@@ -39,7 +39,7 @@ extern "C" int pe_conv3x3_wd_f16(const void* input, const void* packed_weight, c
         return PE_ERR_UNSUPPORTED;
     }
     const long long M = (long long)N * H * W;
-    PE_CHECK_ARG(M * Cin * 2 < (1ll << 32) && M < (1ll << 31), "pe_conv3x3_wd_f16: input larger than 4 GiB");
+    PE_CHECK_ARG(M * Cin * 2 < (1ll << 31), "pe_conv3x3_wd_f16: input larger than 2 GiB (32-bit buffer offsets)");
     const int os = out_stride > 0 ? out_stride : Cout;
     PE_CHECK_ARG(os % 8 == 0, "pe_conv3x3_wd_f16: out_stride must be a multiple of 8");
     pe::ConvWdArgs a{};
@@ -74,7 +74,7 @@ extern "C" int pe_conv3x3_wd_rpn_head_f16(const void* input, const void* packed_
         return PE_ERR_UNSUPPORTED;
     }
     const long long M = (long long)N * H * W;
-    PE_CHECK_ARG(M * Cin * 2 < (1ll << 32) && M < (1ll << 31), "pe_conv3x3_wd_rpn_head_f16: input larger than 4 GiB");
+    PE_CHECK_ARG(M * Cin * 2 < (1ll << 31), "pe_conv3x3_wd_rpn_head_f16: input larger than 2 GiB (32-bit buffer offsets)");
     pe::ConvWdArgs a{};
     a.in = (const _Float16*)input; a.wpk = (const _Float16*)packed_weight; a.bias = bias; a.out = nullptr;
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = 256; a.M = (int)M; a.relu = 1; a.out_stride = 256;
@@ -108,7 +108,7 @@ extern "C" int pe_bottleneck_tail_wd_f16(const void* input, const void* packed_w
         return PE_ERR_UNSUPPORTED;
     }
     const long long M = (long long)N * H * W;
-    PE_CHECK_ARG(M * tail_cout * 2 < (1ll << 32) && M < (1ll << 31), "pe_bottleneck_tail_wd_f16: tensors larger than 4 GiB");
+    PE_CHECK_ARG(M * tail_cout * 2 < (1ll << 31) && M * Cin * 2 < (1ll << 31), "pe_bottleneck_tail_wd_f16: tensors larger than 2 GiB (32-bit buffer offsets)");
     pe::ConvWdArgs a{};
     a.in = (const _Float16*)input; a.wpk = (const _Float16*)packed_weight3x3; a.bias = bias3x3; a.out = nullptr;
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = 256; a.M = (int)M; a.relu = 1; a.out_stride = 256;

@@ -99,7 +99,7 @@ class GeneralizedRCNN:
     # ------------------------------------------------------------------ stages
     def _conv(self, x, name, **kw):
         w, b = self.w.convs[name]
-        if kw.get("kernel") == 3 and name in self.w.wd and self.use_wd and kw.get("residual") is None \
+        if kw.get("kernel") == 3 and name in self.w.wd and self.use_wd and kw.get("residual") is None and x.numel() * 2 < 2 ** 31 \
                 and L.conv_wd_supported(3, 1, x.shape[1], x.shape[2], x.shape[3], w.shape[0]):
             return L.conv3x3_wd(x, self.w.wd[name], b, w.shape[0], relu=kw.get("relu", False), out=kw.get("out"),
                                 out_stride=kw.get("out_stride", 0))
@@ -120,7 +120,8 @@ class GeneralizedRCNN:
                 sc = self._conv(x, p + ".shortcut", kernel=1, stride=stride) if (p + ".shortcut") in self.w.convs else x
                 o = self._conv(x, p + ".conv1", kernel=1, stride=stride, relu=True)
                 tail = self.w.tails.get(p) if self.use_wd and self.fuse_tails else None
-                if tail is not None and L.conv_wd_supported(3, 1, o.shape[1], o.shape[2], o.shape[3], 256):
+                if tail is not None and L.conv_wd_supported(3, 1, o.shape[1], o.shape[2], o.shape[3], 256) \
+                        and o.shape[0] * o.shape[1] * o.shape[2] * self.w.convs[p + ".conv3"][0].shape[0] * 2 < 2 ** 31:
                     # conv2 + ReLU + conv3 + shortcut + ReLU in one launch: the 256-channel intermediate stays on the chip
                     x = L.bottleneck_tail_wd(o, self.w.wd[p + ".conv2"], self.w.convs[p + ".conv2"][1], tail[0], tail[1], sc,
                                              self.w.convs[p + ".conv3"][0].shape[0])
@@ -228,7 +229,7 @@ class GeneralizedRCNN:
             heads = []
             fused = self.w.rpn_head_fused if self.use_wd else None
             for f in feats:
-                if fused is not None and L.conv_wd_supported(3, 1, f.shape[1], f.shape[2], f.shape[3], 256):
+                if fused is not None and f.numel() * 2 < 2 ** 31 and L.conv_wd_supported(3, 1, f.shape[1], f.shape[2], f.shape[3], 256):
                     # StandardRPNHead in one launch: the 256-channel ReLU'd map never goes to HBM
                     heads.append(L.conv3x3_wd_rpn_head(f, self.w.wd["rpn.conv"], self.w.convs["rpn.conv"][1], fused[0], fused[1]))
                     continue
