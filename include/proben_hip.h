@@ -217,7 +217,8 @@ int pe_nms_batched(const float* boxes, const float* scores, const int32_t* idxs,
  * / predict_objectness_logits (proposal_generator/rpn_outputs.py:409-452), Box2BoxTransform.apply_deltas
  * (box_regression.py:73-110) and find_top_rpn_proposals' selection half (rpn_outputs.py:100-145).
  *   level_heads_host[l]: DEVICE pointer to the fused RPN head output of level l, fp32 [N*H*W, head_stride]
- *     (columns 0..2 objectness for anchors a=0..2, columns 3+4a..6+4a the deltas of anchor a);
+ *     (columns 0..2 objectness for anchors a=0..2, columns 3+4a..6+4a the deltas of anchor a); head_stride >= 16,
+ *     a multiple of 4, pointers 16-byte aligned (the logits of a cell are fetched as one 16-byte load, once, into LDS);
  *   level_hw_host [L,2], level_stride_host [L], cell_anchors_host [L,3,4] are HOST arrays;
  *   image_hw [N,2] device int32 (h,w) of the unpadded resized images;
  *   outputs per image: cand_per_image = sum_l min(pre_nms_topk, H*W*3) rows, level-major, each level

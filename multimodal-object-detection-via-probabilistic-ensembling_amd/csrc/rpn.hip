@@ -16,7 +16,7 @@ namespace {
 constexpr int kThreads = 1024;
 constexpr int kMaxTopk = 1024;
 constexpr int kA = 3;
-constexpr int kSlice = 16384;  // anchors per stage-1 slice
+constexpr int kSliceKeys = 16383;  // anchors per stage-1 slice: 5461 whole cells, 64 KiB of keys in LDS
 
 struct RpnLevel {
     const float* head;  // [N*H*W, head_stride]
@@ -128,10 +128,24 @@ __device__ __forceinline__ void block_topk(int total, int k, KeyAt key_at, unsig
     }
 }
 
-// Stage 1 (optional, for big levels): every slice of kSlice anchors finds ITS top-k on its own workgroup, so the
+// The objectness keys of a slice / small level are read from the head rows ONCE (one float4 = the three logits of a
+// cell per thread) into LDS; the four radix passes and the two collection passes of block_topk then run on LDS instead of
+// going back to the 64-byte head rows six times.
+__device__ __forceinline__ void stage_keys(const float* head, int head_stride, int cell0, int cells, unsigned* keys) {
+    for (int c = threadIdx.x; c < cells; c += kThreads) {
+        const float4 v = *reinterpret_cast<const float4*>(head + (size_t)(cell0 + c) * head_stride);   // rows are 16-byte aligned (stride % 4 == 0)
+        keys[c * kA] = ordered_desc(v.x);
+        keys[c * kA + 1] = ordered_desc(v.y);
+        keys[c * kA + 2] = ordered_desc(v.z);
+    }
+    __syncthreads();
+}
+
+// Stage 1 (optional, for big levels): every slice of kSliceKeys anchors finds ITS top-k on its own workgroup, so the
 // 153 600-key p2 level is spread over 10 CUs instead of being one workgroup's 5 passes.  Any global top-k element
 // is in its slice's top-k, so stage 2 (below) stays exact.  Output: (key << 32 | global anchor index) per slice.
 __global__ __launch_bounds__(kThreads) void rpn_slice_kernel(RpnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned keys[];   // kSliceKeys
     __shared__ unsigned hist[256];
     __shared__ unsigned long long cand[kMaxTopk];
     __shared__ unsigned s4[4];
@@ -140,11 +154,12 @@ __global__ __launch_bounds__(kThreads) void rpn_slice_kernel(RpnArgs a) {
     const int L = a.slice_level[sl];
     const RpnLevel& lv = a.lv[L];
     const int total_l = lv.H * lv.W * kA;
-    const int s0 = a.slice_begin[sl];
-    const int total = min(kSlice, total_l - s0);
+    const int s0 = a.slice_begin[sl];                  // slices start at cell boundaries (kSliceKeys % kA == 0)
+    const int total = min(kSliceKeys, total_l - s0);
     const int k = min(lv.topk, total);
     const float* head = lv.head + (size_t)n * lv.H * lv.W * a.head_stride;
-    auto key_at = [&](int i) { const int g = s0 + i; return ordered_desc(head[(size_t)(g / kA) * a.head_stride + (g % kA)]); };
+    stage_keys(head, a.head_stride, s0 / kA, total / kA, keys);
+    auto key_at = [&](int i) { return keys[i]; };
     block_topk(total, k, key_at, cand, hist, wave_cnt, s4);
     unsigned long long* out = a.slice_out + ((size_t)n * a.num_slices + sl) * kMaxTopk;
     const int tid = threadIdx.x;
@@ -152,6 +167,7 @@ __global__ __launch_bounds__(kThreads) void rpn_slice_kernel(RpnArgs a) {
 }
 
 __global__ __launch_bounds__(kThreads) void rpn_select_kernel(RpnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned keys[];   // kSliceKeys
     __shared__ unsigned hist[256];
     __shared__ unsigned long long cand[kMaxTopk];
     __shared__ unsigned s4[4];
@@ -172,8 +188,14 @@ __global__ __launch_bounds__(kThreads) void rpn_select_kernel(RpnArgs a) {
         __syncthreads();
     } else {
         const int total = lv.H * lv.W * kA;
-        auto key_at = [&](int i) { return ordered_desc(head[(size_t)(i / kA) * a.head_stride + (i % kA)]); };
-        block_topk(total, k, key_at, cand, hist, wave_cnt, s4);
+        if (total <= kSliceKeys) {
+            stage_keys(head, a.head_stride, 0, lv.H * lv.W, keys);
+            auto key_at = [&](int i) { return keys[i]; };
+            block_topk(total, k, key_at, cand, hist, wave_cnt, s4);
+        } else {   // no scratch for the two-stage route: the whole level from memory
+            auto key_at = [&](int i) { return ordered_desc(head[(size_t)(i / kA) * a.head_stride + (i % kA)]); };
+            block_topk(total, k, key_at, cand, hist, wave_cnt, s4);
+        }
     }
     // ---- decode survivors ----
     if (tid < k) {
@@ -233,7 +255,7 @@ extern "C" int pe_rpn_select_topk(const float* const* level_heads_host, const in
     PE_CHECK_ARG(num_levels >= 1 && num_levels <= 8, "pe_rpn_select_topk: num_levels %d", num_levels);
     PE_CHECK_ARG(pre_nms_topk >= 1 && pre_nms_topk <= kMaxTopk, "pe_rpn_select_topk: pre_nms_topk %d not in [1,%d]",
                  pre_nms_topk, kMaxTopk);
-    PE_CHECK_ARG(head_stride >= 15, "pe_rpn_select_topk: head_stride %d < 15", head_stride);
+    PE_CHECK_ARG(head_stride >= 16 && head_stride % 4 == 0, "pe_rpn_select_topk: head_stride %d (rows must be 16-byte aligned, >= 16 floats)", head_stride);
     PE_CHECK_ARG(level_heads_host && level_hw_host && level_stride_host && cell_anchors_host && image_hw,
                  "pe_rpn_select_topk: null pointer");
     PE_CHECK_ARG(cand_boxes && cand_scores && cand_level && cand_valid, "pe_rpn_select_topk: null output");
@@ -260,23 +282,31 @@ extern "C" int pe_rpn_select_topk(const float* const* level_heads_host, const in
     int ns = 0;
     for (int l = 0; l < num_levels; ++l) {
         const int tot = a.lv[l].H * a.lv[l].W * kA;
-        const int cnt = (tot + kSlice - 1) / kSlice;
+        const int cnt = (tot + kSliceKeys - 1) / kSliceKeys;
         a.lv[l].first_slice = ns;
         a.lv[l].num_slices = cnt > 1 ? cnt : 0;
         if (cnt > 1) {
-            for (int c = 0; c < cnt && ns < 64; ++c, ++ns) { a.slice_level[ns] = l; a.slice_begin[ns] = c * kSlice; }
+            for (int c = 0; c < cnt && ns < 64; ++c, ++ns) { a.slice_level[ns] = l; a.slice_begin[ns] = c * kSliceKeys; }
         }
     }
     a.num_slices = ns;
+    static_assert(kSliceKeys % kA == 0, "slices are cut at cell boundaries");
+    constexpr size_t key_lds = ((size_t)kSliceKeys * sizeof(unsigned) + 15) / 16 * 16;
+    static bool lds_set = false;
+    if (!lds_set) {   // 64 KiB of keys + ~9 KiB of static LDS is beyond the default 64 KiB cap
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rpn_slice_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)key_lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rpn_select_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)key_lds);
+        lds_set = true;
+    }
     const size_t need = (size_t)N * ns * kMaxTopk * sizeof(unsigned long long);
     if (scratch && ns > 0 && ns < 64 && scratch_bytes >= need) {
         a.slice_out = (unsigned long long*)scratch;
-        hipLaunchKernelGGL(rpn_slice_kernel, dim3(ns, N), dim3(kThreads), 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL(rpn_slice_kernel, dim3(ns, N), dim3(kThreads), key_lds, (hipStream_t)stream, a);
         PE_CHECK_LAUNCH("pe_rpn_select_topk(slices)");
     } else {
         a.slice_out = nullptr;
     }
-    hipLaunchKernelGGL(rpn_select_kernel, dim3(num_levels, N), dim3(kThreads), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(rpn_select_kernel, dim3(num_levels, N), dim3(kThreads), key_lds, (hipStream_t)stream, a);
     PE_CHECK_LAUNCH("pe_rpn_select_topk");
     return PE_OK;
 }
@@ -285,7 +315,7 @@ extern "C" size_t pe_rpn_scratch_bytes(const int32_t* level_hw_host, int32_t num
     size_t ns = 0;
     for (int l = 0; l < num_levels; ++l) {
         const long long tot = (long long)level_hw_host[2 * l] * level_hw_host[2 * l + 1] * kA;
-        const long long cnt = (tot + kSlice - 1) / kSlice;
+        const long long cnt = (tot + kSliceKeys - 1) / kSliceKeys;
         if (cnt > 1) ns += (size_t)cnt;
     }
     return (size_t)N * ns * kMaxTopk * sizeof(unsigned long long);
