@@ -181,6 +181,8 @@ __global__ __launch_bounds__(256) void roi_align_kernel(RoiArgs a) {
             const float* wyr = tabs.w[0][ph];
             const float* wxr = tabs.w[1][pw];
             int rr = 0, c = 0;
+            int poff = 0;                                   // element offset of pixel (rr, c): advanced by adds only (an image's
+            const int step_c = a.C, step_r = (W - nx + 1) * a.C;   // level is < 2^31 elements) - no 64-bit multiplies per tap
             constexpr int MLP = ROI_MLP;   // independent 16-byte loads in flight per lane
             for (int i = 0; i < npx; i += MLP) {
                 half8 h[MLP];
@@ -188,9 +190,14 @@ __global__ __launch_bounds__(256) void roi_align_kernel(RoiArgs a) {
 #pragma unroll
                 for (int u = 0; u < MLP; ++u) {
                     const bool ok = i + u < npx;
-                    w[u] = ok ? wyr[rr] * wxr[c] : 0.f;
-                    h[u] = *reinterpret_cast<const half8*>(base + ((size_t)rr * W + c) * a.C);
-                    if (i + u + 1 < npx && ++c == nx) { c = 0; ++rr; }   // stays on the last pixel past the end
+                    const float wv = wyr[rr] * wxr[c];      // (rr, c) is always a valid table slot: read, then mask
+                    w[u] = ok ? wv : 0.f;
+                    h[u] = *reinterpret_cast<const half8*>(base + poff);
+                    const bool adv = i + u + 1 < npx;       // stays on the last pixel past the end; selects, no branches
+                    const bool wrap = adv && c + 1 == nx;
+                    poff += wrap ? step_r : (adv ? step_c : 0);
+                    c = wrap ? 0 : c + (adv ? 1 : 0);
+                    rr += wrap ? 1 : 0;
                 }
 #pragma unroll
                 for (int u = 0; u < MLP; ++u)
