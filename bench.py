@@ -65,6 +65,7 @@ def parse(argv=None):
     ap.add_argument("--conv-impl", type=int, default=2, help="1: register-staged conv kernel, 2: LDS-DMA conv kernels")
     ap.add_argument("--no-wd", action="store_true", help="A/B: do not use the weights-direct 3x3 kernel")
     ap.add_argument("--no-tail-fusion", action="store_true", help="A/B: run conv2 and conv3 of the res4 bottlenecks as two launches")
+    ap.add_argument("--no-res2-fusion", action="store_true", help="A/B: run res2 as separate conv launches instead of the fused 64-wide chain")
     ap.add_argument("--serial-detectors", action="store_true", help="run the detectors back to back on one stream")
     ap.add_argument("--stagger", type=int, default=3,
                     help="N > 0 (default 3, two-detector configs): throughput mode of the pipeline - detector 2 trails detector 1 by its "
@@ -106,7 +107,7 @@ def maybe_self_launch(args, argv):
 
 
 # ----------------------------------------------------------------------------------------------------------------
-def build_models(cfg, depth, device, use_wd=True, fuse_tails=True):
+def build_models(cfg, depth, device, use_wd=True, fuse_tails=True, fuse_res2=True):
     import proben_amd  # noqa: F401
     from proben_amd.rcnn import DetectorConfig, GeneralizedRCNN
     from proben_amd.synthetic import synthetic_state_dict
@@ -118,6 +119,7 @@ def build_models(cfg, depth, device, use_wd=True, fuse_tails=True):
         m = GeneralizedRCNN(DetectorConfig(num_classes=cfg["K"], input_format=fmt[ch], pixel_mean=mean, pixel_std=(1.0,) * ch), sd, device)
         m.use_wd = use_wd
         m.fuse_tails = fuse_tails
+        m.fuse_res2 = fuse_res2
         models.append(m)
         sds.append(sd)
     return models, sds
@@ -336,7 +338,7 @@ def main(argv=None):
     cfg = CONFIGS[args.config]
     depth = args.depth or cfg["depth"]
     B = args.batch or cfg["batch"]
-    models, sds = build_models(cfg, depth, dev, use_wd=not args.no_wd, fuse_tails=not args.no_tail_fusion)
+    models, sds = build_models(cfg, depth, dev, use_wd=not args.no_wd, fuse_tails=not args.no_tail_fusion, fuse_res2=not args.no_res2_fusion)
     from proben_amd import _lib
     _lib.check(_lib.lib().pe_set_conv_impl(args.conv_impl), "pe_set_conv_impl")
     if args.tile256 >= 0:

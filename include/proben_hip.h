@@ -148,6 +148,20 @@ int pe_conv_wd_pack_tail(const void* weight, void* packed, int32_t tail_cout, in
 int pe_bottleneck_tail_wd_f16(const void* input, const void* packed_weight3x3, const float* bias3x3, const void* packed_tail,
                               const float* tail_bias, const void* residual, void* output, int32_t N, int32_t H, int32_t W,
                               int32_t Cin, int32_t tail_cout, void* stream);
+/* A 64-channel-wide stride-1 BottleneckBlock from its 3x3 on, plus the next block's first convolution, in ONE launch (res2:
+ * modeling/backbone/resnet.py:107-221 with bottleneck_channels = 64, out_channels = 256; build_resnet_backbone :558-572):
+ *     t2 = relu(conv2_3x3(t1) + bias2);  out = relu(conv3(t2) + bias3 + shortcut);  [t1_next = relu(conv1_next(out) + bias1n)]
+ * t1 [N,H,W,64] fp16 is relu(conv1(x)) of this block.  shortcut_src: the block input x [N,H,W,256] (identity shortcut), or -
+ * has_shortcut_conv - the input s [N,H,W,64] of the first block's shortcut convolution (64 -> 256, folded BN, bias_sc).
+ * out [N,H,W,256] fp16; t1_next [N,H,W,64] fp16 when has_next.  Any H, W; tensors < 2 GiB.  The intermediate t2, the shortcut
+ * convolution's output and the re-read of `out` by the next conv1 never touch HBM.
+ * pe_bneck64_pack: w2 [64][3][3][64], w3 [256][64], wsc [256][64] or NULL, w1n [64][256] or NULL (fp16, the layouts
+ * pe_conv2d_nhwc_f16 takes) -> one fragment-ordered stream of pe_bneck64_packed_bytes(wsc != NULL, w1n != NULL) bytes. */
+size_t pe_bneck64_packed_bytes(int32_t has_shortcut_conv, int32_t has_next);
+int pe_bneck64_pack(const void* w2, const void* w3, const void* wsc, const void* w1n, void* packed, void* stream);
+int pe_bneck64_f16(const void* t1, const void* shortcut_src, const void* packed, const float* bias2, const float* bias3,
+                   const float* bias_sc, const float* bias1n, void* out, void* t1_next, int32_t N, int32_t H, int32_t W,
+                   int32_t has_shortcut_conv, int32_t has_next, void* stream);
 int pe_conv_wd_pack_head(const void* head_weight, void* packed, int32_t rows, int32_t C, void* stream);
 int pe_conv3x3_wd_rpn_head_f16(const void* input, const void* packed_weight, const float* bias, const void* packed_head,
                                const float* head_bias16, float* head_out, int32_t N, int32_t H, int32_t W, int32_t Cin,

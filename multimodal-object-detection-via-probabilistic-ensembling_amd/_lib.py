@@ -24,6 +24,9 @@ SIGNATURES = {
     "pe_conv3x3_wd_f16": [c_void_p] * 4 + [c_int] * 7 + [c_void_p],
     "pe_conv_wd_pack_tail": [c_void_p] * 2 + [c_int] * 2 + [c_void_p],
     "pe_bottleneck_tail_wd_f16": [c_void_p] * 7 + [c_int] * 5 + [c_void_p],
+    "pe_bneck64_packed_bytes": [c_int] * 2,
+    "pe_bneck64_pack": [c_void_p] * 6,
+    "pe_bneck64_f16": [c_void_p] * 9 + [c_int] * 5 + [c_void_p],
     "pe_conv_wd_pack_head": [c_void_p] * 2 + [c_int] * 2 + [c_void_p],
     "pe_conv3x3_wd_rpn_head_f16": [c_void_p] * 6 + [c_int] * 4 + [c_void_p],
     "pe_preprocess_pack": [c_void_p] + [c_int] * 11 + [c_void_p] * 4,
@@ -45,7 +48,8 @@ SIGNATURES = {
                          c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p],
     "pe_boxhead_finalize": [c_void_p] + [c_int] * 7 + [c_void_p] * 18,
 }
-_RESTYPE = {"pe_last_error": ctypes.c_char_p, "pe_nms_scratch_bytes": ctypes.c_size_t, "pe_rpn_scratch_bytes": ctypes.c_size_t}
+_RESTYPE = {"pe_last_error": ctypes.c_char_p, "pe_nms_scratch_bytes": ctypes.c_size_t, "pe_rpn_scratch_bytes": ctypes.c_size_t,
+             "pe_bneck64_packed_bytes": ctypes.c_size_t}
 
 
 class HipLibraryError(RuntimeError):

@@ -20,7 +20,7 @@ ARCH = "gfx950"
 
 # Per-source extra flags.  The detection post-ops and ProbEn take discrete decisions on
 # IoU / score thresholds, so they must round like the reference's separate mul/add/div.
-EXTRA = {"default": ["-ffp-contract=off"], "conv_igemm.hip": [], "conv_igemm2.hip": [], "conv_wd.hip": [], "stem.hip": []}
+EXTRA = {"default": ["-ffp-contract=off"], "conv_igemm.hip": [], "conv_igemm2.hip": [], "conv_wd.hip": [], "bneck64.hip": [], "stem.hip": []}
 
 
 def hipcc():

@@ -231,6 +231,46 @@ def bottleneck_tail_wd(x, packed3x3, bias3x3, packed_tail, tail_bias, residual, 
     return out
 
 
+def bneck64_pack(w2, w3, wsc=None, w1n=None):
+    """Fragment-ordered weight stream of `bneck64`: w2 [64,3,3,64], w3 [256,64] (or [256,1,1,64]), wsc [256,64] | None (first
+    block's shortcut convolution), w1n [64,256] | None (the next block's conv1); all fp16, BN folded."""
+    _lib.require_cuda(w2, w3)
+    assert tuple(w2.shape) == (64, 3, 3, 64) and w3.numel() == 256 * 64 and w2.dtype == torch.float16
+    for w in (w2, w3, wsc, w1n):
+        assert w is None or (w.is_contiguous() and w.dtype == torch.float16 and w.numel() in (64 * 576, 256 * 64))
+    nbytes = _lib.lib().pe_bneck64_packed_bytes(int(wsc is not None), int(w1n is not None))
+    packed = torch.empty(nbytes // 2, dtype=torch.float16, device=w2.device)
+    _lib.check(_lib.lib().pe_bneck64_pack(_lib.ptr(w2), _lib.ptr(w3), _lib.ptr(wsc), _lib.ptr(w1n), _lib.ptr(packed), _lib.stream()), "pe_bneck64_pack")
+    return packed
+
+
+def bneck64(t1, shortcut_src, packed, bias2, bias3, bias_sc=None, bias1n=None, out=None, t1_next=None):
+    """out = relu(conv3(relu(conv2_3x3(t1))) + shortcut) of a 64-wide bottleneck block and, when bias1n is given (packed with
+    w1n), t1_next = relu(conv1_next(out)), in one launch.  shortcut_src: x [N,H,W,256] (identity) or, when bias_sc is given
+    (packed with wsc), the shortcut convolution's input [N,H,W,64].  Returns (out, t1_next | None)."""
+    _lib.require_cuda(t1, shortcut_src, packed, bias2, bias3)
+    N, H, W, C = t1.shape
+    has_sc, has_next = bias_sc is not None, bias1n is not None
+    assert C == 64 and t1.is_contiguous() and shortcut_src.is_contiguous() and t1.dtype == torch.float16
+    assert tuple(shortcut_src.shape) == (N, H, W, 64 if has_sc else 256)
+    assert packed.numel() * 2 == _lib.lib().pe_bneck64_packed_bytes(int(has_sc), int(has_next)), "packed stream does not match the requested stages"
+    if out is None:
+        out = torch.empty((N, H, W, 256), dtype=torch.float16, device=t1.device)
+    if has_next and t1_next is None:
+        t1_next = torch.empty((N, H, W, 64), dtype=torch.float16, device=t1.device)
+    st = _lib.lib().pe_bneck64_f16(_lib.ptr(t1), _lib.ptr(shortcut_src), _lib.ptr(packed), _lib.ptr(bias2), _lib.ptr(bias3), _lib.ptr(bias_sc),
+                                   _lib.ptr(bias1n), _lib.ptr(out), _lib.ptr(t1_next if has_next else None), N, H, W, int(has_sc), int(has_next),
+                                   _lib.stream())
+    _lib.check(st, "pe_bneck64_f16")
+    if PROFILE is not None:
+        M = N * H * W
+        PROFILE.append({"variant": f"bneck64_kernel<{int(has_sc)}, {int(has_next)}>", "shape": f"N{N} {H}x{W} 64->64->256{'+sc' if has_sc else '+id'}{'->64' if has_next else ''} f320",
+                        "flops": 2.0 * M * 64 * (576 + 256 + (64 if has_sc else 0) + (256 if has_next else 0)),
+                        "bytes": float(M * 2 * (64 + (64 if has_sc else 256) + 256 + (64 if has_next else 0)) + packed.numel() * 2),
+                        "replay": (lambda: bneck64(t1, shortcut_src, packed, bias2, bias3, bias_sc, bias1n, out=out, t1_next=t1_next))})
+    return out, (t1_next if has_next else None)
+
+
 def conv_wd_pack_head(weight2d):
     """[rows <= 16, 256] fp16 head weight (objectness + anchor deltas) -> the fragment-ordered 16 KiB block of the fused RPN head."""
     _lib.require_cuda(weight2d)

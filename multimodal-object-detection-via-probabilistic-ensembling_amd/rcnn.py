@@ -80,6 +80,7 @@ class GeneralizedRCNN:
         self.training = False
         self.use_wd = True   # weights-direct 3x3 kernel where the geometry allows (A/B switch)
         self.fuse_tails = True   # conv2 + conv3 of a bottleneck in one launch where conv2 is 256 wide (A/B switch)
+        self.fuse_res2 = True    # res2 as the fused 64-wide bottleneck chain of csrc/bneck64.hip (A/B switch)
 
     def eval(self):
         return self
@@ -114,6 +115,21 @@ class GeneralizedRCNN:
             x = L.maxpool3x3s2_nhwc(x)
         outs = []
         for si, nb in enumerate(STAGE_BLOCKS[self.depth]):
+            chain = self.w.chains64.get(f"{bu}.res{si + 2}") if self.fuse_res2 else None
+            if chain is not None and si == 0 and len(chain) == nb and x.shape[0] * x.shape[1] * x.shape[2] * 512 < 2 ** 31:
+                # res2 in 1 + nb launches: conv1 of the first block, then per block 3x3 -> conv3 (+ shortcut) -> the next block's conv1;
+                # neither the 64-channel intermediates' round trips, nor the shortcut convolution's output, nor a re-read of a block
+                # output by the following conv1 go through HBM
+                t1 = self._conv(x, f"{bu}.res2.0.conv1", kernel=1, relu=True)
+                src = x
+                for blk in chain:
+                    src, t1 = L.bneck64(t1, src, blk["packed"], blk["b2"], blk["b3"], blk["bsc"], blk["b1n"])
+                x = src
+                outs.append(x)
+                hook = getattr(self, "stage_hook", None)
+                if hook is not None:
+                    hook(si + 2)
+                continue
             for bi in range(nb):
                 p = f"{bu}.res{si + 2}.{bi}"
                 stride = 2 if (bi == 0 and si > 0) else 1

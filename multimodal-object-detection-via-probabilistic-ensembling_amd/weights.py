@@ -121,6 +121,34 @@ class PackedDetector:
                 w3, b3 = self.convs[name[:-1] + "3"]
                 if w3.shape[3] == 256 and w3.shape[0] % 256 == 0:
                     self.tails[name[: -len(".conv2")]] = (L.conv_wd_pack_tail(w3.reshape(w3.shape[0], 256).contiguous()), b3)
+        # 64-wide stride-1 stages (res2): every block from its 3x3 on, fused with the next block's conv1 (csrc/bneck64.hip)
+        self.chains64 = {}
+        for name in self.convs:
+            if not name.endswith(".0.conv2") or tuple(self.convs[name][0].shape) != (64, 3, 3, 64):
+                continue
+            stage = name[: -len(".0.conv2")]
+            blocks, bi = [], 0
+            while f"{stage}.{bi}.conv2" in self.convs:
+                blocks.append(f"{stage}.{bi}")
+                bi += 1
+            ok = all(tuple(self.convs[b + ".conv2"][0].shape) == (64, 3, 3, 64) and tuple(self.convs[b + ".conv3"][0].shape) == (256, 1, 1, 64) and
+                     tuple(self.convs[b + ".conv1"][0].shape)[:3] == (64, 1, 1) for b in blocks)
+            ok = ok and all(self.convs[b + k][1] is not None for b in blocks for k in (".conv1", ".conv2", ".conv3"))
+            ok = ok and all(tuple(self.convs[b + ".conv1"][0].shape) == (64, 1, 1, 256) for b in blocks[1:])
+            ok = ok and all((b + ".shortcut") not in self.convs for b in blocks[1:])
+            sc0 = self.convs.get(blocks[0] + ".shortcut")
+            ok = ok and sc0 is not None and tuple(sc0[0].shape) == (256, 1, 1, 64) and sc0[1] is not None
+            if not ok:
+                continue
+            chain = []
+            for i, b in enumerate(blocks):
+                nxt = self.convs[blocks[i + 1] + ".conv1"] if i + 1 < len(blocks) else None
+                sc = sc0 if i == 0 else None
+                packed = L.bneck64_pack(self.convs[b + ".conv2"][0], self.convs[b + ".conv3"][0].reshape(256, 64),
+                                        sc[0].reshape(256, 64) if sc else None, nxt[0].reshape(64, 256) if nxt else None)
+                chain.append({"packed": packed, "b2": self.convs[b + ".conv2"][1], "b3": self.convs[b + ".conv3"][1],
+                              "bsc": sc[1] if sc else None, "b1n": nxt[1] if nxt else None})
+            self.chains64[stage] = chain
         # fused StandardRPNHead (3x3 + ReLU + 1x1 in one launch) when the RPN is 256 wide
         self.rpn_head_fused = None
         hw, hb = self.convs["rpn.head"]

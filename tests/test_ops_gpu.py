@@ -224,6 +224,48 @@ def test_fused_bottleneck_tail_matches_two_launch_path_and_torch(L, shape):
     torch.testing.assert_close(outs[0].float(), ref, rtol=5e-3, atol=5e-3)
 
 
+@pytest.mark.parametrize("shape", [(2, 8, 64, True, True), (1, 7, 70, False, True), (3, 5, 32, False, False), (2, 13, 130, True, False), (1, 50, 64, False, True)])
+def test_fused_bneck64_chain_matches_torch_and_unfused_kernels(L, shape):
+    """A res2 bottleneck from its 3x3 on + the next block's conv1 (backbone/resnet.py:107-221) in one launch == torch fp32 with
+    the fp16 roundings of the unfused pipeline (t2 and the block output are fp16 tensors there) == the unfused kernels;
+    ragged tiles (7 x 70, 13 x 130 pixels vs 4 x 64 tiles), identity and convolution shortcuts, with / without the next conv1,
+    run twice (race screen)."""
+    N, H, W, sc, nxt = shape
+    F = torch.nn.functional
+    g = torch.Generator(device="cpu").manual_seed(41)
+    t1 = torch.randn(N, 64, H, W, generator=g).cuda().half().relu()
+    src = (torch.randn(N, 64 if sc else 256, H, W, generator=g).cuda().half()).relu()
+    w2 = (torch.randn(64, 64, 3, 3, generator=g) / 24.0).cuda().half()
+    b2 = torch.randn(64, generator=g).cuda() * 0.5
+    w3 = (torch.randn(256, 64, 1, 1, generator=g) / 8.0).cuda().half()
+    b3 = torch.randn(256, generator=g).cuda() * 0.5
+    wsc = (torch.randn(256, 64, 1, 1, generator=g) / 8.0).cuda().half() if sc else None
+    bsc = torch.randn(256, generator=g).cuda() * 0.5 if sc else None
+    w1n = (torch.randn(64, 256, 1, 1, generator=g) / 16.0).cuda().half() if nxt else None
+    b1n = torch.randn(64, generator=g).cuda() * 0.5 if nxt else None
+    t2 = F.conv2d(t1.float(), w2.float(), b2, padding=1).relu().half().float()
+    short = F.conv2d(src.float(), wsc.float(), bsc) if sc else src.float()
+    out_ref = (F.conv2d(t2, w3.float(), b3) + short).relu()
+    ohwi = lambda w: w.permute(0, 2, 3, 1).contiguous()
+    packed = L.bneck64_pack(ohwi(w2), ohwi(w3).reshape(256, 64), ohwi(wsc).reshape(256, 64) if sc else None, ohwi(w1n).reshape(64, 256) if nxt else None)
+    runs = [L.bneck64(nhwc(t1), nhwc(src), packed, b2, b3, bsc, b1n) for _ in range(2)]
+    torch.cuda.synchronize()
+    assert torch.equal(runs[0][0], runs[1][0])
+    out, t1n = runs[0]
+    torch.testing.assert_close(out.float(), out_ref.permute(0, 2, 3, 1), rtol=5e-3, atol=5e-3)
+    if nxt:
+        assert torch.equal(runs[0][1], runs[1][1])
+        t1n_ref = F.conv2d(out.permute(0, 3, 1, 2).float(), w1n.float(), b1n).relu()      # from the kernel's own fp16 block output
+        torch.testing.assert_close(t1n.float(), t1n_ref.permute(0, 2, 3, 1), rtol=5e-3, atol=5e-3)
+    else:
+        assert t1n is None
+    # the unfused kernels on the same data
+    u2 = L.conv2d_nhwc(nhwc(t1), ohwi(w2), b2, kernel=3, relu=True)
+    r = L.conv2d_nhwc(nhwc(src), ohwi(wsc), bsc, kernel=1) if sc else nhwc(src)
+    u3 = L.conv2d_nhwc(u2, ohwi(w3), b3, kernel=1, relu=True, residual=r, residual_mode=1)
+    torch.testing.assert_close(out.float(), u3.float(), rtol=4e-3, atol=4e-3)
+
+
 def test_conv3x3_weights_direct_matches_lds_kernel_and_rejects_other_geometry(L):
     """Same fp16 inputs through the weights-direct and the LDS-DMA 3x3 kernels: both accumulate in fp32 over the same
     products, so they agree to fp32 summation-order noise; unsupported widths are refused loudly."""
