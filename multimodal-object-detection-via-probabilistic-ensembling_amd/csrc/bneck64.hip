@@ -219,6 +219,19 @@ __global__ __launch_bounds__(256, 2) void bneck64_kernel(B64Args a) {
             for (int q = 0; q < 4; ++q) sfr[i][q] = rv[i][q];
     }
     const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)(M * 512), 0x00020000);
+    unsigned char* stg = smem + wave * (64 * SROW);       // 64 pixel rows of 128 B (+ pad) per wave, inside the dead slab
+    // staging row k * 8 + lane / 8 = pixel column x0 + that index of this wave's image row
+    const unsigned srow0 = (unsigned)(img + (long long)gy * a.W + x0) + (lane >> 3);
+    const int scol0 = gy < a.H ? x0 + (lane >> 3) : 0x40000000;
+    auto srow_off = [&](int k, unsigned bytes_per_px, unsigned col_bytes) {
+        return scol0 + k * 8 < a.W ? (srow0 + k * 8) * bytes_per_px + col_bytes + (lane & 7) * 16 : 0xFFFFFFF0u;
+    };
+    auto stage_rows = [&](const half8 (&v)[2][4], int) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *reinterpret_cast<half8*>(stg + (i * 32 + px) * SROW + h * 64 + q * 16) = v[i][q];
+    };
     int s2 = 0;   // running phase-2 step (compile-time after unrolling): stream position P1_STEPS + s2
     auto step_mfma = [&](int sidx, float16v (&acc)[2][2], const half8& bf0, const half8& bf1) {
         const int g = P1_STEPS + sidx;
@@ -265,29 +278,40 @@ __global__ __launch_bounds__(256, 2) void bneck64_kernel(B64Args a) {
                     of[i][q][e] = (_Float16)fmaxf(v, 0.f);
                 }
         if (!SC && c + 1 < 4) res_load(c + 1);   // next chunk's shortcut rows: in flight across the stores and the MFMAs below
+        // Stores: a lane owns 64 bytes of one pixel, so a direct store instruction is 64 scattered 16-byte pieces - partial
+        // line writes that cost ~0.1 ms per launch against whole lines (measured).  The chunk goes through a wave-private LDS
+        // patch (the slab is dead in this phase) and leaves as whole 128-byte rows: lane l -> row l / 8, piece l % 8.
+        stage_rows(of, 128);
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int k = 0; k < 8; ++k) {
+            const half8 v = *reinterpret_cast<const half8*>(stg + (k * 8 + (lane >> 3)) * SROW + (lane & 7) * 16);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4v, v), rout, srow_off(k, 512u, c * 128), 0, 0);
+        }
+        if (NEXT) {   // B fragments of the chunk: read back from the staging patch (the lane's own 16-byte pieces) rather than kept in registers
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4v, of[i][q]), rout,
-                                                       pvalid[i] ? poff[i] * 512u + c * 128 + h * 64 + q * 16 : 0xFFFFFFF0u, 0, 0);
-        if (NEXT) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { step_mfma(s2, acc4, of[0][j], of[1][j]); ++s2; }
+            for (int j = 0; j < 4; ++j) {
+                const half8 f0 = *reinterpret_cast<const half8*>(stg + px * SROW + h * 64 + j * 16);
+                const half8 f1 = *reinterpret_cast<const half8*>(stg + (32 + px) * SROW + h * 64 + j * 16);
+                step_mfma(s2, acc4, f0, f1);
+                ++s2;
+            }
         }
     }
     if (NEXT) {
         const __amdgpu_buffer_rsrc_t rt1n = __builtin_amdgcn_make_buffer_rsrc(a.t1n, 0, (int)(M * 128), 0x00020000);
+        half8 tn[2][4];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                half8 v;
+            for (int q = 0; q < 4; ++q)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = (_Float16)fmaxf(acc4[q >> 1][i][(q & 1) * 8 + e], 0.f);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4v, v), rt1n,
-                                                       pvalid[i] ? poff[i] * 128u + h * 64 + q * 16 : 0xFFFFFFF0u, 0, 0);
-            }
+                for (int e = 0; e < 8; ++e) tn[i][q][e] = (_Float16)fmaxf(acc4[q >> 1][i][(q & 1) * 8 + e], 0.f);
+        stage_rows(tn, 128);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const half8 v = *reinterpret_cast<const half8*>(stg + (k * 8 + (lane >> 3)) * SROW + (lane & 7) * 16);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4v, v), rt1n, srow_off(k, 128u, 0), 0, 0);
+        }
     }
 }
 
