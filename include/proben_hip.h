@@ -210,7 +210,8 @@ int pe_stem_conv7x7_maxpool_f16(const void* x, const void* w_packed, const float
  * Batched class-aware greedy NMS (float32).  Replaces detectron2.layers.batched_nms
  * (layers/nms.py:20-37) -> torchvision.ops.boxes.batched_nms / nms (torchvision 0.13.0), call sites
  * proposal_generator/rpn_outputs.py:147, roi_heads/fast_rcnn.py:130, demo/FLIR/demo_probEn.py:64.
- *   boxes [B,n_max,4], scores [B,n_max], idxs [B,n_max] (class / level id, may be NULL),
+ *   boxes [B,n_max,4], scores [B,n_max], idxs [B,n_max] (class / level id, may be NULL; any int32 - ids in [0, 2^18) get
+ *   the per-class fast path: tiles of the suppression matrix between different classes are never computed),
  *   counts [B] rows used per image (NULL = n_max), valid [B,n_max] optional row mask.
  *   mode 0: coordinate trick (boxes + idx*(max+1)), mode 1: suppress only within equal idx ("vanilla").
  *   out_keep [B,max_out] input-row indices in score-descending order (ties: lower index first),

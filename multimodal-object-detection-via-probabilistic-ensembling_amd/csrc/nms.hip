@@ -8,11 +8,15 @@
 // "coordinate trick"), PE_NMS_CLASS compares class ids instead (== one nms per class, "vanilla").
 // Order rule: score descending, ties by input index ascending (stable descending sort).
 //
-// Three launches per batch, all images in flight at once:
-//   1. sort:  one 1024-thread block per image, bitonic sort of 64-bit keys (~score | index) in LDS
-//   2. mask:  64x64 box tiles -> suppression bit matrix [n][ceil(n/64)] (one wavefront row per block)
-//   3. scan:  one wavefront per image walks the sorted boxes, OR-ing kept rows into a 64-lane register
-//             mask (lane l owns words l, l+64, ...), early exit at max_out kept.
+// Suppression only ever happens inside a class (mode 1 by definition; mode 0 because boxes of different classes are moved
+// max_coord + 1 apart and cannot intersect), so the work is organised per class:
+//   1. sort:  one 1024-thread block per image, bitonic sort of 64-bit keys (class | ~score | index) in LDS: boxes end up
+//             grouped by class, score-descending inside a class; the class segments are listed
+//   2. mask:  64 x 64 tiles of the sorted order -> suppression bit matrix; tiles whose row and column class ranges are
+//             disjoint (4 of every 5 for the five-level RPN input) are zero-filled without a single IoU
+//   3. scan + order: one 1024-thread block per image; every wavefront runs the greedy scan of whole class segments
+//             (<= 16 chunks for an RPN level instead of 73 for the image, early exit at max_out per class), then the block
+//             re-sorts the survivors by (~score | index) and emits the first max_out.
 #include "common.h"
 
 namespace {
@@ -40,6 +44,9 @@ struct NmsArgs {
     int32_t* sidx;         // [B, n_max] sorted -> input row
     int32_t* scls;         // [B, n_max]
     int32_t* nvalid;       // [B]
+    unsigned* sord;        // [B, n_max] order-preserving score bits of the sorted rows
+    int32_t* seg_start;    // [B, n_max] first sorted position of every class segment (any order)
+    int32_t* nseg;         // [B]
     unsigned long long* mask;  // [B, n_max, words]
     int words;
     int32_t* out_keep;     // [B, max_out]
@@ -50,19 +57,20 @@ __global__ __launch_bounds__(kSortThreads) void nms_sort_kernel(NmsArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);
     __shared__ float red[kSortThreads / 64];
-    __shared__ int cnt_s;
+    __shared__ int cnt_s, seg_s;
     const int b = blockIdx.x, tid = threadIdx.x;
     const int n = a.counts ? min(a.counts[b], a.n_max) : a.n_max;
     const float* sc = a.scores + (size_t)b * a.n_max;
     const float* bx = a.boxes + (size_t)b * a.n_max * 4;
-    if (tid == 0) cnt_s = 0;
+    if (tid == 0) { cnt_s = 0; seg_s = 0; }
     __syncthreads();
     float mx = -INFINITY;
     int local_cnt = 0;
     for (int i = tid; i < a.n_pad; i += kSortThreads) {
         unsigned long long k = ~0ull;
         if (i < n && (!a.valid || a.valid[(size_t)b * a.n_max + i])) {
-            k = ((unsigned long long)ordered_desc(sc[i]) << 32) | (unsigned)i;
+            const unsigned long long c = a.idxs ? ((unsigned)a.idxs[(size_t)b * a.n_max + i] & 0x3FFFFu) : 0u;   // class: 18 bits
+            k = (c << 46) | ((unsigned long long)ordered_desc(sc[i]) << 14) | (unsigned)i;                       // index: 14 bits (n_max <= 16384)
             ++local_cnt;
             mx = fmaxf(mx, fmaxf(fmaxf(bx[i * 4], bx[i * 4 + 1]), fmaxf(bx[i * 4 + 2], bx[i * 4 + 3])));
         }
@@ -93,14 +101,18 @@ __global__ __launch_bounds__(kSortThreads) void nms_sort_kernel(NmsArgs a) {
     if (tid == 0) a.nvalid[b] = nv;
     const float off1 = mx + 1.0f;
     for (int p = tid; p < nv; p += kSortThreads) {
-        const int i = (int)(keys[p] & 0xFFFFFFFFu);
+        const int i = (int)(keys[p] & 0x3FFFu);
         const int c = a.idxs ? a.idxs[(size_t)b * a.n_max + i] : 0;
+        a.sord[(size_t)b * a.n_max + p] = (unsigned)(keys[p] >> 14);
+        if (p == 0 || (keys[p] >> 46) != (keys[p - 1] >> 46)) a.seg_start[(size_t)b * a.n_max + atomicAdd(&seg_s, 1)] = p;
         const float off = a.mode == 0 ? (float)c * off1 : 0.f;
         float* o = a.sboxes + ((size_t)b * a.n_max + p) * 4;
         o[0] = bx[i * 4] + off; o[1] = bx[i * 4 + 1] + off; o[2] = bx[i * 4 + 2] + off; o[3] = bx[i * 4 + 3] + off;
         a.sidx[(size_t)b * a.n_max + p] = i;
         a.scls[(size_t)b * a.n_max + p] = c;
     }
+    __syncthreads();
+    if (tid == 0) a.nseg[b] = seg_s;
 }
 
 // grid (col_tiles, row_tiles, B), block 64: thread t handles sorted row (row_tile*64 + t) against 64 columns.
@@ -113,6 +125,14 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(NmsArgs a) {
     __shared__ int cc[64];
     const int t = threadIdx.x;
     const float* sb = a.sboxes + (size_t)b * a.n_max * 4;
+    {   // sorted by (masked) class: the tile's columns all come after its rows; disjoint class ranges -> nothing to suppress
+        const int* cls = a.scls + (size_t)b * a.n_max;
+        const unsigned row_last = (unsigned)cls[min(row0 + 63, nv - 1)] & 0x3FFFFu, col_first = (unsigned)cls[col0] & 0x3FFFFu;
+        if (col_first > row_last) {
+            if (row0 + t < nv) a.mask[((size_t)b * a.n_max + row0 + t) * a.words + blockIdx.x] = 0ull;
+            return;
+        }
+    }
     if (col0 + t < nv) {
         cb[t][0] = sb[(col0 + t) * 4]; cb[t][1] = sb[(col0 + t) * 4 + 1];
         cb[t][2] = sb[(col0 + t) * 4 + 2]; cb[t][3] = sb[(col0 + t) * 4 + 3];
@@ -128,7 +148,7 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(NmsArgs a) {
     const int jn = min(64, nv - col0);
     for (int j = (col0 == row0 ? t + 1 : 0); j < jn; ++j) {
         if (col0 + j <= r) continue;
-        if (a.mode == 1 && cc[j] != rc) continue;
+        if (cc[j] != rc) continue;   // mode 1 by definition; mode 0: shifted apart by (max_coord + 1) per class -> IoU 0
         const float w = fmaxf(0.f, fminf(x2, cb[j][2]) - fmaxf(x1, cb[j][0]));
         const float h = fmaxf(0.f, fminf(y2, cb[j][3]) - fmaxf(y1, cb[j][1]));
         const float inter = w * h;
@@ -139,54 +159,114 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(NmsArgs a) {
     a.mask[((size_t)b * a.n_max + r) * a.words + blockIdx.x] = bits;
 }
 
-// One wavefront per image, 64 sorted boxes per step ("pull" form):
-//   1. the removed word of chunk c = OR over ALL boxes kept so far of their mask word c: the kept list lives
-//      in LDS, lanes stride over it with independent loads (one memory latency per chunk), then a wave OR;
-//   2. lane l fetches the DIAGONAL word of row 64c+l and the chunk is resolved in registers with scalar
-//      readlanes (64 short steps, no memory);
-//   3. survivors are appended to the kept list / output in order; early exit at max_out.
-__global__ __launch_bounds__(64) void nms_scan_kernel(NmsArgs a) {
+// One 1024-thread block per image.  Phase 1: wavefront w runs the greedy scan of class segments w, w + 16, ... ("pull" form,
+// 64 sorted boxes per step):
+//   1. the removed word of chunk c = OR over the boxes of this segment kept so far of their mask word c: the kept list
+//      lives in LDS, lanes stride over it with independent loads (one memory latency per chunk), then a wave OR;
+//   2. lane l fetches the DIAGONAL word of row 64c+l and the chunk is resolved in registers with scalar readlanes;
+//   3. survivors are appended to the segment's kept list and flagged; a segment stops at max_out survivors (no class can
+//      place more than that in the final top max_out).
+// Phase 2: the flagged rows' (~score | input index) keys are bitonic-sorted by the whole block; the first max_out leave.
+constexpr int kScanThreads = 1024;
+__global__ __launch_bounds__(kScanThreads) void nms_scan_order_kernel(NmsArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned short* kept_pos = reinterpret_cast<unsigned short*>(smem);  // sorted positions of kept boxes
-    const int b = blockIdx.x, lane = threadIdx.x;
+    // phase 1 layout: kept_pos [n_max] u16 | flags [n_pad / 32] u32;  phase 2: keys [n_pad] u64 over the same bytes
+    unsigned short* kept_pos = reinterpret_cast<unsigned short*>(smem);
+    unsigned* flags = reinterpret_cast<unsigned*>(smem + (((size_t)a.n_max * 2 + 15) & ~(size_t)15));
+    __shared__ int total_s;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nv = a.nvalid[b];
-    const int words = (nv + 63) / 64;
-    int kept = 0;
+    const int nseg = a.nseg[b];
     const unsigned long long* mk = a.mask + (size_t)b * a.n_max * a.words;
-    for (int c = 0; c < words && kept < a.max_out; ++c) {
-        const int i0 = c * 64;
-        // ---- 1. pull: who among the kept boxes suppresses members of this chunk ----
-        unsigned long long rem = 0;
-        for (int k = lane; k < kept; k += 64) {
-            const int p = kept_pos[k];
-            if ((p >> 6) < c) rem |= mk[(size_t)p * a.words + c];  // rows of earlier chunks only (same chunk: step 2)
+    for (int i = tid; i < a.n_pad / 32; i += kScanThreads) flags[i] = 0u;
+    if (tid == 0) total_s = 0;
+    __syncthreads();
+    for (int sgi = wave; sgi < nseg; sgi += kScanThreads / 64) {
+        const int p0 = a.seg_start[(size_t)b * a.n_max + sgi];
+        const int cls0 = a.scls[(size_t)b * a.n_max + p0];
+        // segment end: the class changes (segments are listed in no particular order, so walk the class array)
+        int p1;
+        {
+            int lo = p0, hi = nv;   // first position >= p0 whose class differs (classes are sorted: binary search on equality run)
+            const unsigned key0 = (unsigned)cls0 & 0x3FFFFu;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (((unsigned)a.scls[(size_t)b * a.n_max + mid] & 0x3FFFFu) == key0) lo = mid + 1; else hi = mid;
+            }
+            p1 = lo;
         }
-        for (int o = 32; o > 0; o >>= 1) rem |= __shfl_xor(rem, o);
-        // ---- 2. resolve the chunk in registers ----
-        const int row = i0 + lane;
-        const unsigned long long diag = row < nv ? mk[(size_t)row * a.words + c] : 0ull;
-        const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
-        const int nb = min(64, nv - i0);
-        unsigned long long keepmask = 0;
-        int kept_here = 0;
-        for (int bit = 0; bit < nb; ++bit) {
-            if ((rem >> bit) & 1ull) continue;          // wave-uniform
-            if (kept + kept_here >= a.max_out) break;
-            keepmask |= 1ull << bit;
-            ++kept_here;
-            const unsigned lo = __builtin_amdgcn_readlane(dlo, bit), hi = __builtin_amdgcn_readlane(dhi, bit);
-            rem |= ((unsigned long long)hi << 32) | lo;
+        unsigned short* kp = kept_pos + p0;
+        int kept = 0;
+        for (int c = p0 >> 6; c <= ((p1 - 1) >> 6) && kept < a.max_out; ++c) {
+            const int i0 = c * 64;
+            unsigned long long rem = 0;
+            for (int k = lane; k < kept; k += 64) {
+                const int p = kp[k];
+                if ((p >> 6) < c) rem |= mk[(size_t)p * a.words + c];
+            }
+            for (int o = 32; o > 0; o >>= 1) rem |= __shfl_xor(rem, o);
+            const int row = i0 + lane;
+            const bool mine = row >= p0 && row < p1;
+            const unsigned long long diag = mine ? mk[(size_t)row * a.words + c] : 0ull;
+            const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
+            const int b_lo = max(p0 - i0, 0), b_hi = min(p1 - i0, 64);
+            unsigned long long keepmask = 0;
+            int kept_here = 0;
+            for (int bit = b_lo; bit < b_hi; ++bit) {
+                if ((rem >> bit) & 1ull) continue;          // wave-uniform
+                if (kept + kept_here >= a.max_out) break;
+                keepmask |= 1ull << bit;
+                ++kept_here;
+                const unsigned lo = __builtin_amdgcn_readlane(dlo, bit), hi = __builtin_amdgcn_readlane(dhi, bit);
+                rem |= ((unsigned long long)hi << 32) | lo;
+            }
+            if ((keepmask >> lane) & 1ull) {
+                kp[kept + __popcll(keepmask & pe::lanemask_lt())] = (unsigned short)row;
+                atomicOr(&flags[row >> 5], 1u << (row & 31));
+            }
+            kept += kept_here;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the kept list is re-read by other lanes of this wave
+            __builtin_amdgcn_wave_barrier();
         }
-        // ---- 3. emit the survivors in order ----
-        if ((keepmask >> lane) & 1ull) {
-            const int slot = kept + __popcll(keepmask & pe::lanemask_lt());
-            kept_pos[slot] = (unsigned short)row;
-            a.out_keep[(size_t)b * a.max_out + slot] = a.sidx[(size_t)b * a.n_max + row];
-        }
-        kept += kept_here;
-        __syncthreads();
+        if (lane == 0) atomicAdd(&total_s, kept);
     }
-    if (lane == 0) a.out_counts[b] = kept;
+    __syncthreads();
+    // ---- phase 2: keys of the flagged rows (flags are read into registers before the key array overwrites them) ----
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);
+    constexpr int KPT = 16;   // n_pad <= 16384 = 1024 threads x 16
+    unsigned long long mykeys[KPT];
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
+        const int p = tid + j * kScanThreads;
+        unsigned long long k = ~0ull;
+        if (p < nv && ((flags[p >> 5] >> (p & 31)) & 1u))
+            k = ((unsigned long long)(a.sord[(size_t)b * a.n_max + p] & 0xFFFFFFFFu) << 32) | (unsigned)a.sidx[(size_t)b * a.n_max + p];
+        mykeys[j] = k;
+    }
+    const int total = total_s;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
+        const int p = tid + j * kScanThreads;
+        if (p < a.n_pad) keys[p] = mykeys[j];
+    }
+    __syncthreads();
+    for (int k = 2; k <= a.n_pad; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < a.n_pad; i += kScanThreads) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const unsigned long long x = keys[i], y = keys[ixj];
+                    const bool up = (i & k) == 0;
+                    if ((x > y) == up) { keys[i] = y; keys[ixj] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    const int nout = min(total, a.max_out);
+    for (int i = tid; i < nout; i += kScanThreads) a.out_keep[(size_t)b * a.max_out + i] = (int)(keys[i] & 0xFFFFFFFFu);
+    if (tid == 0) a.out_counts[b] = nout;
 }
 
 }  // namespace
@@ -196,9 +276,10 @@ extern "C" size_t pe_nms_scratch_bytes(int32_t B, int32_t n_max) {
     size_t s = 0;
     s += (size_t)B * n_max * 4 * sizeof(float);    // sboxes
     s += (size_t)B * n_max * sizeof(int32_t) * 2;  // sidx, scls
-    s += (size_t)B * sizeof(int32_t) + 64;         // nvalid
+    s += (size_t)B * sizeof(int32_t) * 2 + 128;    // nvalid, nseg
+    s += (size_t)B * n_max * sizeof(int32_t) * 2;  // sord, seg_start
     s += (size_t)B * n_max * words * 8;            // mask
-    return s + 256;
+    return s + 512;
 }
 
 extern "C" int pe_nms_batched(const float* boxes, const float* scores, const int32_t* idxs, const int32_t* counts,
@@ -232,6 +313,9 @@ extern "C" int pe_nms_batched(const float* boxes, const float* scores, const int
     a.sidx = (int32_t*)carve((size_t)B * n_max * 4);
     a.scls = (int32_t*)carve((size_t)B * n_max * 4);
     a.nvalid = (int32_t*)carve((size_t)B * 4);
+    a.nseg = (int32_t*)carve((size_t)B * 4);
+    a.sord = (unsigned*)carve((size_t)B * n_max * 4);
+    a.seg_start = (int32_t*)carve((size_t)B * n_max * 4);
     a.out_keep = out_keep; a.out_counts = out_counts;
     const size_t lds = (size_t)a.n_pad * 8;
     if (lds > 64 * 1024)
@@ -240,7 +324,10 @@ extern "C" int pe_nms_batched(const float* boxes, const float* scores, const int
     PE_CHECK_LAUNCH("pe_nms_batched(sort)");
     hipLaunchKernelGGL(nms_mask_kernel, dim3(a.words, a.words, B), dim3(64), 0, st, a);
     PE_CHECK_LAUNCH("pe_nms_batched(mask)");
-    hipLaunchKernelGGL(nms_scan_kernel, dim3(B), dim3(64), (size_t)std::min(max_out, n_max) * 2 + 16, st, a);
-    PE_CHECK_LAUNCH("pe_nms_batched(scan)");
+    const size_t lds2 = std::max((size_t)a.n_pad * 8, (((size_t)n_max * 2 + 15) & ~(size_t)15) + (size_t)a.n_pad / 8 + 16);
+    if (lds2 + 256 > 64 * 1024)   // + the kernel's static LDS
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nms_scan_order_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+    hipLaunchKernelGGL(nms_scan_order_kernel, dim3(B), dim3(kScanThreads), lds2, st, a);
+    PE_CHECK_LAUNCH("pe_nms_batched(scan + order)");
     return PE_OK;
 }
