@@ -452,6 +452,26 @@ def test_nms_batched_raw_valid_mask_and_counts(L):
         np.testing.assert_array_equal(keep[i, : int(cnt[i])].cpu().numpy(), want)
 
 
+def test_nms_per_class_fast_path_keeps_the_generic_contract(L):
+    """The kernels group boxes by class (ids masked to 18 bits) and skip cross-class tiles.  Contract checks: 80 classes, a
+    max_out below the number of survivors (the global top max_out by score across classes), and ids that are negative or
+    collide modulo 2^18 (they share a segment but must still never suppress each other) - all against the oracle."""
+    from oracle import nms as O
+    g = torch.Generator().manual_seed(77)
+    n = 3000
+    b = rand_boxes(g, n, span=250.0)
+    s = torch.rand(n, generator=g)
+    c80 = torch.randint(0, 80, (n,), generator=g).int()
+    keep, cnt = L.nms_batched_raw(b.cuda()[None], s.cuda()[None], c80.cuda()[None], None, None, 0.5, 0, 150)
+    want = O.batched_nms_f32(b.numpy(), s.numpy(), c80.numpy(), 0.5, mode="trick")[:150]
+    np.testing.assert_array_equal(keep[0, : int(cnt[0])].cpu().numpy(), want)
+    ids = torch.tensor([5, 5 + (1 << 18), -3, 70000, 5 + (1 << 19)], dtype=torch.int32)
+    cw = ids[torch.randint(0, 5, (n,), generator=g)]
+    keep, cnt = L.nms_batched_raw(b.cuda()[None], s.cuda()[None], cw.cuda()[None], None, None, 0.5, 1, n)
+    want = O.batched_nms_f32(b.numpy(), s.numpy(), cw.numpy(), 0.5, mode="vanilla")
+    np.testing.assert_array_equal(keep[0, : int(cnt[0])].cpu().numpy(), want)
+
+
 # ------------------------------------------------------------------------------------------------ RPN
 @pytest.mark.parametrize("two_stage", [False, True])
 def test_rpn_select_matches_oracle(two_stage):
