@@ -245,6 +245,11 @@ def roofline_leg(step, layers_path="", reps=10):
     k3 = max(pure, key=lambda k: agg[k][1], default=None)
     if k3 is not None and k3 != dom:
         out["conv3x3"] = with_traffic(describe(k3))
+    # ... and the HBM-bound 1x1 class (the dominant kernel of rounds 1-2 until the res4 tails and res2 were fused; it and the fused
+    # bottleneck tail now take about the same share of a step, so which of the two is "dominant" can flip between runs)
+    k1 = max((k for k in agg if k.startswith("conv_igemm2_kernel<128, 128")), key=lambda k: agg[k][2], default=None)
+    if k1 is not None and k1 != dom:
+        out["conv1x1"] = with_traffic(describe(k1))
     out["method"] = ("avg_launch_ms = HIP-event timing of every distinct launch replayed back-to-back on the launch stream; "
                      "agrees with rocprofv3 --kernel-trace --stats of `bench.py --serial-detectors` (profiles/).  In the default "
                      "two-stream run co-running kernels stretch each other's durations while the step gets shorter.")
