@@ -138,8 +138,8 @@ __global__ __launch_bounds__(256, 2) void bneck64_kernel(B64Args a) {
     }
     // Weight stream: L2 -> registers -> LDS ring -> A fragments.  All four waves (and every pixel block) consume the same
     // 2 KiB per K-step, and a wave has only 4 MFMAs per K-step to hide an L2 round trip behind, so the workgroup fetches each
-    // 8 KiB chunk (4 K-steps) once, cooperatively, four chunks ahead (three register stages = 24 registers per lane), and parks it in a two-slot LDS
-    // ring; one barrier per chunk both publishes chunk k + 1 and retires the reads of chunk k - 1.
+    // 8 KiB chunk (4 K-steps) once, cooperatively, four chunks ahead (three register stages = 24 registers per lane), and parks
+    // it in a two-slot LDS ring; one barrier per chunk both publishes chunk k + 1 and retires the reads of chunk k - 1.
     constexpr int TOTAL = P1_STEPS + P2_TOTAL, NCHUNK = TOTAL / 4;
     static_assert(TOTAL % 4 == 0, "whole chunks");
     unsigned char* wlds = smem + SLAB_BYTES;
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256, 2) void bneck64_kernel(B64Args a) {
     auto srow_off = [&](int k, unsigned bytes_per_px, unsigned col_bytes) {
         return scol0 + k * 8 < a.W ? (srow0 + k * 8) * bytes_per_px + col_bytes + (lane & 7) * 16 : 0xFFFFFFF0u;
     };
-    auto stage_rows = [&](const half8 (&v)[2][4], int) {
+    auto stage_rows = [&](const half8 (&v)[2][4]) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(256, 2) void bneck64_kernel(B64Args a) {
         // Stores: a lane owns 64 bytes of one pixel, so a direct store instruction is 64 scattered 16-byte pieces - partial
         // line writes that cost ~0.1 ms per launch against whole lines (measured).  The chunk goes through a wave-private LDS
         // patch (the slab is dead in this phase) and leaves as whole 128-byte rows: lane l -> row l / 8, piece l % 8.
-        stage_rows(of, 128);
+        stage_rows(of);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const half8 v = *reinterpret_cast<const half8*>(stg + (k * 8 + (lane >> 3)) * SROW + (lane & 7) * 16);
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256, 2) void bneck64_kernel(B64Args a) {
             for (int q = 0; q < 4; ++q)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) tn[i][q][e] = (_Float16)fmaxf(acc4[q >> 1][i][(q & 1) * 8 + e], 0.f);
-        stage_rows(tn, 128);
+        stage_rows(tn);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const half8 v = *reinterpret_cast<const half8*>(stg + (k * 8 + (lane >> 3)) * SROW + (lane & 7) * 16);
