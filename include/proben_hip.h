@@ -279,6 +279,19 @@ int pe_roi_align_nhwc(const void* const* feats_host, const int32_t* feat_hw_host
                       const int32_t* counts, int32_t pooled_h, int32_t pooled_w, int32_t sampling_ratio,
                       int32_t aligned, void* output, int32_t* out_level, void* stream);
 
+/* ROIAlign backward (training half).  Replaces roi_align_backward of detectron2._C
+ * (layers/csrc/ROIAlign/ROIAlign.h:86-115, ROIAlign_cuda.cu:141-306,369-420; same arithmetic as ROIAlign_cpu.cpp:221-394)
+ * behind _ROIAlign.backward (layers/roi_align.py:26-42) and, with num_levels == 4, the backward of ROIPooler's per-level
+ * scatter.  Arguments as pe_roi_align_nhwc; grad_output [R, pooled_h, pooled_w, C] (dtype 0 = fp16, 1 = fp32);
+ * grad_feats_host[l]: DEVICE pointers to fp32 [N, H_l, W_l, C] gradients that are ACCUMULATED into (the caller zeroes
+ * them); rows beyond counts[n] contribute nothing.  fp32 atomic adds: the summation order over overlapping ROIs is not
+ * defined (as in the reference's CUDA kernel). */
+int pe_roi_align_backward_nhwc(const void* grad_output, int32_t dtype, const int32_t* feat_hw_host, const float* scales_host,
+                               int32_t num_levels, int32_t N, int32_t C, const float* rois, int32_t rois_have_batch_index,
+                               int32_t num_rois, int32_t per_image, const int32_t* counts, int32_t pooled_h,
+                               int32_t pooled_w, int32_t sampling_ratio, int32_t aligned, float* const* grad_feats_host,
+                               void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Box-head post-processing.  Replaces FastRCNNOutputs.inference / fast_rcnn_inference_single_image
  * (modeling/roi_heads/fast_rcnn.py:43-147,345-360,417-452) and detector_postprocess

@@ -235,7 +235,124 @@ __global__ __launch_bounds__(256) void roi_align_kernel(RoiArgs a) {
         Vec<T>::store(out + (size_t)bin * a.C + cv * V, acc);
     }
 }
+// ---- backward (training half) ----------------------------------------------------------------------------
+// Replaces RoIAlignBackwardFeature / ROIAlign_backward_cuda (layers/csrc/ROIAlign/ROIAlign_cuda.cu:141-306,369-420; same
+// arithmetic as ROIAlign_cpu.cpp:221-394) behind _ROIAlign.backward (layers/roi_align.py:26-42), and - with four levels - the
+// backward of ROIPooler.forward's per-level scatter (modeling/poolers.py:180-235) in the same launch.
+// Same thread mapping as the forward: one block per ROI, a thread owns V consecutive channels of one bin and hands
+// grad * w / count to the four corners of every sample with hardware fp32 atomic adds (NHWC: the V atomics of a tap are
+// adjacent addresses).  Like the reference's CUDA kernel the summation order over overlapping ROIs is not defined.
+struct RoiBwdArgs {
+    RoiArgs f;            // geometry as in the forward; f.out = grad_output [R, ph, pw, C]; f.feat unused
+    float* gin[4];        // [N, H_l, W_l, C] fp32 per level, accumulated into
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void roi_align_backward_kernel(RoiBwdArgs b) {
+    const RoiArgs& a = b.f;
+    constexpr int V = Vec<T>::N;
+    const int r = blockIdx.x;
+    int img;
+    float bx1, by1, bx2, by2;
+    if (a.rois5) {
+        const float* p = a.rois + (size_t)r * 5;
+        img = (int)p[0]; bx1 = p[1]; by1 = p[2]; bx2 = p[3]; by2 = p[4];
+    } else {
+        img = r / a.per_image;
+        const float* p = a.rois + (size_t)r * 4;
+        bx1 = p[0]; by1 = p[1]; bx2 = p[2]; by2 = p[3];
+        if (a.counts && (r - img * a.per_image) >= a.counts[img]) return;   // padded slot: its output was zeros, no gradient
+    }
+    int lvl = 0;
+    if (a.num_levels > 1) {
+        const float area = (bx2 - bx1) * (by2 - by1);
+        const float sz = sqrtf(area);
+        float lv = floorf((float)a.canonical_level + log2f(sz / a.canonical_size + 2.220446049250313e-16f));
+        lv = fminf(fmaxf(lv, (float)a.min_level), (float)a.max_level);
+        lvl = (int)lv - a.min_level;
+    }
+    const int H = a.fh[lvl], W = a.fw[lvl];
+    const float scale = a.scale[lvl];
+    float* gin = b.gin[lvl] + (size_t)img * H * W * a.C;
+    const float offset = a.aligned ? 0.5f : 0.0f;
+    const float start_w = bx1 * scale - offset, start_h = by1 * scale - offset;
+    const float end_w = bx2 * scale - offset, end_h = by2 * scale - offset;
+    float roi_w = end_w - start_w, roi_h = end_h - start_h;
+    if (!a.aligned) { roi_w = fmaxf(roi_w, 1.f); roi_h = fmaxf(roi_h, 1.f); }
+    const float bin_h = roi_h / (float)a.ph, bin_w = roi_w / (float)a.pw;
+    const int grid_h = a.sampling_ratio > 0 ? a.sampling_ratio : (int)ceilf(roi_h / (float)a.ph);
+    const int grid_w = a.sampling_ratio > 0 ? a.sampling_ratio : (int)ceilf(roi_w / (float)a.pw);
+    const float count = (float)(grid_h * grid_w);
+    const int cvec = a.C / V;
+    const int items = a.ph * a.pw * cvec;
+    const T* gout = reinterpret_cast<const T*>(a.out) + (size_t)r * a.ph * a.pw * a.C;
+    for (int it = threadIdx.x; it < items; it += blockDim.x) {
+        const int cv = it % cvec, bin = it / cvec;
+        const int ph = bin / a.pw, pw = bin - ph * a.pw;
+        float g[V];
+        Vec<T>::load(gout + (size_t)bin * a.C + cv * V, g);
+        for (int iy = 0; iy < grid_h; ++iy) {
+            const float yy = start_h + ph * bin_h + (float)(iy + .5f) * bin_h / (float)grid_h;
+            for (int ix = 0; ix < grid_w; ++ix) {
+                const float xx = start_w + pw * bin_w + (float)(ix + .5f) * bin_w / (float)grid_w;
+                float x = xx, y = yy;
+                if (y < -1.0f || y > (float)H || x < -1.0f || x > (float)W) continue;
+                if (y <= 0) y = 0;
+                if (x <= 0) x = 0;
+                int y_low = (int)y, x_low = (int)x, y_high, x_high;
+                if (y_low >= H - 1) { y_high = y_low = H - 1; y = (float)y_low; } else y_high = y_low + 1;
+                if (x_low >= W - 1) { x_high = x_low = W - 1; x = (float)x_low; } else x_high = x_low + 1;
+                const float ly = y - y_low, lx = x - x_low, hy = 1.f - ly, hx = 1.f - lx;
+                const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+                float* p1 = gin + ((size_t)y_low * W + x_low) * a.C + cv * V;
+                float* p2 = gin + ((size_t)y_low * W + x_high) * a.C + cv * V;
+                float* p3 = gin + ((size_t)y_high * W + x_low) * a.C + cv * V;
+                float* p4 = gin + ((size_t)y_high * W + x_high) * a.C + cv * V;
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    unsafeAtomicAdd(p1 + e, g[e] * w1 / count);
+                    unsafeAtomicAdd(p2 + e, g[e] * w2 / count);
+                    unsafeAtomicAdd(p3 + e, g[e] * w3 / count);
+                    unsafeAtomicAdd(p4 + e, g[e] * w4 / count);
+                }
+            }
+        }
+    }
+}
 }  // namespace
+
+extern "C" int pe_roi_align_backward_nhwc(const void* grad_output, int32_t dtype, const int32_t* feat_hw_host,
+                                          const float* scales_host, int32_t num_levels, int32_t N, int32_t C, const float* rois,
+                                          int32_t rois_have_batch_index, int32_t num_rois, int32_t per_image,
+                                          const int32_t* counts, int32_t pooled_h, int32_t pooled_w, int32_t sampling_ratio,
+                                          int32_t aligned, float* const* grad_feats_host, void* stream) {
+    PE_CHECK_ARG(num_levels == 1 || num_levels == 4, "pe_roi_align_backward_nhwc: num_levels %d not in {1,4}", num_levels);
+    PE_CHECK_ARG(dtype == 0 || dtype == 1, "pe_roi_align_backward_nhwc: dtype %d (0 = fp16, 1 = fp32 grad_output)", dtype);
+    PE_CHECK_ARG(feat_hw_host && scales_host && grad_feats_host, "pe_roi_align_backward_nhwc: null level tables");
+    PE_CHECK_ARG(C % (dtype == 0 ? 8 : 4) == 0, "pe_roi_align_backward_nhwc: C %d not a multiple of the vector width", C);
+    PE_CHECK_ARG(pooled_h > 0 && pooled_w > 0, "pe_roi_align_backward_nhwc: bad pooled size");
+    if (num_rois == 0) return PE_OK;
+    PE_CHECK_ARG(rois && grad_output, "pe_roi_align_backward_nhwc: null pointer");
+    PE_CHECK_ARG(rois_have_batch_index || per_image > 0, "pe_roi_align_backward_nhwc: per_image required in boxes mode");
+    RoiBwdArgs b{};
+    RoiArgs& a = b.f;
+    for (int l = 0; l < num_levels; ++l) {
+        a.fh[l] = feat_hw_host[2 * l]; a.fw[l] = feat_hw_host[2 * l + 1]; a.scale[l] = scales_host[l];
+        b.gin[l] = grad_feats_host[l];
+        PE_CHECK_ARG(b.gin[l] != nullptr, "pe_roi_align_backward_nhwc: null gradient pointer");
+    }
+    a.num_levels = num_levels; a.N = N; a.C = C; a.rois = rois; a.rois5 = rois_have_batch_index;
+    a.per_image = per_image; a.counts = counts; a.R = num_rois; a.ph = pooled_h; a.pw = pooled_w;
+    a.sampling_ratio = sampling_ratio; a.aligned = aligned;
+    a.min_level = 2; a.max_level = 5; a.canonical_level = 4; a.canonical_size = 224.f;
+    a.out = const_cast<void*>(grad_output);
+    if (dtype == 0)
+        hipLaunchKernelGGL((roi_align_backward_kernel<_Float16>), dim3(num_rois), dim3(256), 0, (hipStream_t)stream, b);
+    else
+        hipLaunchKernelGGL((roi_align_backward_kernel<float>), dim3(num_rois), dim3(256), 0, (hipStream_t)stream, b);
+    PE_CHECK_LAUNCH("pe_roi_align_backward_nhwc");
+    return PE_OK;
+}
 
 extern "C" int pe_roi_align_nhwc(const void* const* feats_host, const int32_t* feat_hw_host, const float* scales_host,
                                  int32_t num_levels, int32_t N, int32_t C, int32_t dtype, const float* rois,

@@ -93,9 +93,64 @@ def roi_align_nhwc(feats, rois, *, scales, pooled, sampling_ratio=0, aligned=Tru
     return (out, lv) if want_levels else out
 
 
+def roi_align_backward_nhwc(grad_output, rois, feat_shapes, *, scales, sampling_ratio=0, aligned=True, counts=None, per_image=0,
+                            num_rois=None):
+    """Adjoint of roi_align_nhwc: grad_output [R,ph,pw,C] (fp16 or fp32) -> list of fp32 [N,H_l,W_l,C] gradients, one per
+    level of `feat_shapes` (1 or 4 (N,H,W,C) tuples); training half of layers/roi_align.py:26-42 / poolers.py:180-235."""
+    _lib.require_cuda(grad_output, rois)
+    g = grad_output.contiguous()
+    R, ph, pw, C = g.shape
+    dtype = 0 if g.dtype == torch.float16 else 1
+    if dtype == 1:
+        g = g.float()
+    have_b = rois.dim() == 2 and rois.shape[1] == 5
+    N = feat_shapes[0][0]
+    grads = [torch.zeros(tuple(fs), dtype=torch.float32, device=g.device) for fs in feat_shapes]
+    nl = len(grads)
+    ptrs = (ctypes.c_void_p * nl)(*[t.data_ptr() for t in grads])
+    hw = (ctypes.c_int32 * (2 * nl))(*sum([[fs[1], fs[2]] for fs in feat_shapes], []))
+    sc = (ctypes.c_float * nl)(*scales)
+    st = _lib.lib().pe_roi_align_backward_nhwc(_lib.ptr(g), dtype, hw, sc, nl, N, C, _lib.ptr(rois.contiguous()), int(have_b),
+                                               R if num_rois is None else num_rois, int(per_image), _lib.ptr(counts), ph, pw,
+                                               int(sampling_ratio), int(bool(aligned)), ptrs, _lib.stream())
+    _lib.check(st, "pe_roi_align_backward_nhwc")
+    return grads
+
+
+class _ROIAlignFunction(torch.autograd.Function):
+    """layers/roi_align.py:10-49 (`_ROIAlign`): forward and backward both run the gfx950 kernels (NHWC inside)."""
+
+    @staticmethod
+    def forward(ctx, input, rois, output_size, spatial_scale, sampling_ratio, aligned):
+        ctx.save_for_backward(rois)
+        ctx.cfg = (tuple(output_size), spatial_scale, sampling_ratio, aligned, tuple(input.shape), input.dtype)
+        C = input.shape[1]
+        x = input.detach().permute(0, 2, 3, 1).contiguous()
+        if x.dtype not in (torch.float16, torch.float32):
+            x = x.float()
+        pad = (-C) % (8 if x.dtype == torch.float16 else 4)
+        if pad:
+            x = torch.nn.functional.pad(x, (0, pad))
+        out = roi_align_nhwc([x], rois.float(), scales=[spatial_scale], pooled=tuple(output_size), sampling_ratio=sampling_ratio, aligned=aligned)
+        return out[..., :C].permute(0, 3, 1, 2).contiguous().to(input.dtype)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        (rois,) = ctx.saved_tensors
+        output_size, spatial_scale, sampling_ratio, aligned, in_shape, in_dtype = ctx.cfg
+        N, C, H, W = in_shape
+        g = grad_output.detach().permute(0, 2, 3, 1).contiguous().float()
+        pad = (-C) % 4
+        if pad:
+            g = torch.nn.functional.pad(g, (0, pad))
+        (gin,) = roi_align_backward_nhwc(g, rois.float(), [(N, H, W, C + pad)], scales=[spatial_scale], sampling_ratio=sampling_ratio, aligned=aligned)
+        return gin[..., :C].permute(0, 3, 1, 2).contiguous().to(in_dtype), None, None, None, None, None
+
+
 class ROIAlign:
     """Drop-in for detectron2.layers.ROIAlign (layers/roi_align.py:51-96): NCHW input, rois [K,5],
-    returns [K,C,ph,pw] in the input dtype.  (The detector itself stays in NHWC and calls roi_align_nhwc.)"""
+    returns [K,C,ph,pw] in the input dtype; differentiable with respect to the input like the reference's autograd Function.
+    (The detector itself stays in NHWC and calls roi_align_nhwc.)"""
 
     def __init__(self, output_size, spatial_scale, sampling_ratio, aligned=True):
         self.output_size = (output_size, output_size) if isinstance(output_size, int) else tuple(output_size)
@@ -106,16 +161,7 @@ class ROIAlign:
     def __call__(self, input, rois):
         assert rois.dim() == 2 and rois.size(1) == 5
         _lib.require_cuda(input, rois)
-        C = input.shape[1]
-        x = input.detach().permute(0, 2, 3, 1).contiguous()
-        if x.dtype not in (torch.float16, torch.float32):
-            x = x.float()
-        pad = (-C) % (8 if x.dtype == torch.float16 else 4)
-        if pad:
-            x = torch.nn.functional.pad(x, (0, pad))
-        out = roi_align_nhwc([x], rois.float(), scales=[self.spatial_scale], pooled=self.output_size,
-                             sampling_ratio=self.sampling_ratio, aligned=self.aligned)
-        return out[..., :C].permute(0, 3, 1, 2).contiguous().to(input.dtype)
+        return _ROIAlignFunction.apply(input, rois, self.output_size, self.spatial_scale, self.sampling_ratio, self.aligned)
 
     forward = __call__
 

@@ -33,3 +33,22 @@ def roi_align_forward(input, rois, spatial_scale, pooled_h, pooled_w, sampling_r
     if st != 0:
         raise RuntimeError("ROIs in ROIAlign cannot have non-negative size!")
     return out
+
+
+def roi_align_backward(grad, rois, spatial_scale, pooled_h, pooled_w, batch_size, channels, height, width, sampling_ratio, aligned):
+    """Same signature as the reference's `_C.roi_align_backward` (layers/csrc/ROIAlign/ROIAlign.h:86-115): grad [K,C,ph,pw]
+    -> grad_input [N,C,H,W] float32."""
+    g = grad.detach().contiguous().float()
+    r = rois.detach().contiguous().float()
+    K = r.shape[0]
+    out = torch.zeros((batch_size, channels, height, width), dtype=torch.float32)
+    if K == 0:
+        return out
+    L = _L()
+    L.oracle_roi_align_backward.restype = ctypes.c_int
+    st = L.oracle_roi_align_backward(
+        ctypes.c_void_p(g.data_ptr()), batch_size, channels, height, width, ctypes.c_void_p(r.data_ptr()), K,
+        ctypes.c_float(spatial_scale), pooled_h, pooled_w, sampling_ratio, int(bool(aligned)), ctypes.c_void_p(out.data_ptr()))
+    if st != 0:
+        raise RuntimeError("ROIs in ROIAlign do not have non-negative size!")
+    return out

@@ -562,6 +562,43 @@ def test_roi_align_fp16_and_dead_rows(L):
     assert float(got[41:].abs().max()) == 0.0
 
 
+def test_roi_align_backward_matches_oracle_and_autograd(L):
+    """Training half: the backward kernel == the oracle's restatement of ROIAlign_cpu.cpp:221-394 (atomics:
+    tolerance, not bits), rows beyond counts contribute nothing, and `layers.ROIAlign` is differentiable end to end."""
+    from oracle import roi_align as RA
+    g = torch.Generator().manual_seed(8)
+    N, C, H, W, P = 2, 16, 25, 32, 20
+    boxes = torch.stack([rand_boxes(g, P, span=420, wh=200) for _ in range(N)])
+    counts = torch.tensor([P, 7], dtype=torch.int32)
+    go = torch.randn(N * P, 7, 7, C, generator=g)
+    for dt, tol in ((torch.float32, 1e-5), (torch.float16, 2e-3)):
+        (gin,) = L.roi_align_backward_nhwc(go.to(dt).cuda(), boxes.cuda(), [(N, H, W, C)], scales=[1 / 16], counts=counts.cuda(), per_image=P)
+        rois = torch.cat([torch.cat([torch.full((int(counts[i]), 1), float(i)), boxes[i, : int(counts[i])]], 1) for i in range(N)])
+        live = torch.cat([go[i * P: i * P + int(counts[i])] for i in range(N)]).to(dt).float()
+        ref = RA.roi_align_backward(live.permute(0, 3, 1, 2), rois, 1 / 16, 7, 7, N, C, H, W, 0, True)
+        torch.testing.assert_close(gin.permute(0, 3, 1, 2).cpu(), ref, rtol=tol, atol=tol)
+    # four FPN levels in one launch: the same rule assigns the level in forward and backward
+    shapes = [(N, 200 // s, 256 // s, 8) for s in (1, 2, 4, 8)]
+    big = torch.stack([rand_boxes(g, P, span=700, wh=500) for _ in range(N)])
+    go4 = torch.randn(N * P, 7, 7, 8, generator=g)
+    grads = L.roi_align_backward_nhwc(go4.cuda(), big.cuda(), shapes, scales=[1 / 4, 1 / 8, 1 / 16, 1 / 32], per_image=P)
+    feats = [torch.zeros(sh, device="cuda") for sh in shapes]
+    _, lv = L.roi_align_nhwc(feats, big.cuda(), scales=[1 / 4, 1 / 8, 1 / 16, 1 / 32], pooled=(7, 7), per_image=P, want_levels=True)
+    rois = torch.cat([torch.cat([torch.full((P, 1), float(i)), big[i]], 1) for i in range(N)])
+    for l, sc in enumerate((1 / 4, 1 / 8, 1 / 16, 1 / 32)):
+        sel = (lv.cpu() == l).nonzero().squeeze(1)
+        ref = RA.roi_align_backward(go4[sel].permute(0, 3, 1, 2), rois[sel], sc, 7, 7, N, 8, shapes[l][1], shapes[l][2], 0, True)
+        torch.testing.assert_close(grads[l].permute(0, 3, 1, 2).cpu(), ref, rtol=1e-5, atol=1e-5)
+    # autograd through the module (layers/roi_align.py:10-49)
+    x = torch.randn(1, 3, 12, 14, generator=g).cuda().requires_grad_()
+    r = torch.tensor([[0, 1.0, 2.0, 11.0, 9.0], [0, 0.0, 0.0, 5.5, 5.5]]).cuda()
+    y = L.ROIAlign((3, 3), 0.5, 2, aligned=True)(x, r)
+    w = torch.randn(y.shape, generator=g).cuda()
+    (y * w).sum().backward()
+    ref = RA.roi_align_backward(w.cpu(), r.cpu(), 0.5, 3, 3, 1, 3, 12, 14, 2, True)
+    torch.testing.assert_close(x.grad.cpu(), ref, rtol=1e-5, atol=1e-5)
+
+
 # ------------------------------------------------------------------------------------------------ box head
 def test_boxhead_matches_oracle_quirks():
     import ctypes
