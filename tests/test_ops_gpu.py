@@ -571,7 +571,7 @@ def test_roi_align_backward_matches_oracle_and_autograd(L):
     boxes = torch.stack([rand_boxes(g, P, span=420, wh=200) for _ in range(N)])
     counts = torch.tensor([P, 7], dtype=torch.int32)
     go = torch.randn(N * P, 7, 7, C, generator=g)
-    for dt, tol in ((torch.float32, 1e-5), (torch.float16, 2e-3)):
+    for dt, tol in ((torch.float32, 5e-5), (torch.float16, 2e-3)):   # fp32: summation order differs (atomics vs the oracle's sequential adds)
         (gin,) = L.roi_align_backward_nhwc(go.to(dt).cuda(), boxes.cuda(), [(N, H, W, C)], scales=[1 / 16], counts=counts.cuda(), per_image=P)
         rois = torch.cat([torch.cat([torch.full((int(counts[i]), 1), float(i)), boxes[i, : int(counts[i])]], 1) for i in range(N)])
         live = torch.cat([go[i * P: i * P + int(counts[i])] for i in range(N)]).to(dt).float()
@@ -588,7 +588,7 @@ def test_roi_align_backward_matches_oracle_and_autograd(L):
     for l, sc in enumerate((1 / 4, 1 / 8, 1 / 16, 1 / 32)):
         sel = (lv.cpu() == l).nonzero().squeeze(1)
         ref = RA.roi_align_backward(go4[sel].permute(0, 3, 1, 2), rois[sel], sc, 7, 7, N, 8, shapes[l][1], shapes[l][2], 0, True)
-        torch.testing.assert_close(grads[l].permute(0, 3, 1, 2).cpu(), ref, rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(grads[l].permute(0, 3, 1, 2).cpu(), ref, rtol=5e-5, atol=5e-5)
     # autograd through the module (layers/roi_align.py:10-49)
     x = torch.randn(1, 3, 12, 14, generator=g).cuda().requires_grad_()
     r = torch.tensor([[0, 1.0, 2.0, 11.0, 9.0], [0, 0.0, 0.0, 5.5, 5.5]]).cuda()
@@ -596,7 +596,7 @@ def test_roi_align_backward_matches_oracle_and_autograd(L):
     w = torch.randn(y.shape, generator=g).cuda()
     (y * w).sum().backward()
     ref = RA.roi_align_backward(w.cpu(), r.cpu(), 0.5, 3, 3, 1, 3, 12, 14, 2, True)
-    torch.testing.assert_close(x.grad.cpu(), ref, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(x.grad.cpu(), ref, rtol=5e-5, atol=5e-5)
 
 
 # ------------------------------------------------------------------------------------------------ box head
