@@ -1,0 +1,318 @@
+// Round 3, VERDICT r02 item 1: can ONE CU run an MFMA-bound wave set and an HBM-bound wave set at the same time and keep
+// both rates - i.e. is an "alternate phases by construction" schedule of the fused bottleneck tail worth building - or does
+// the chip's power management give the overlap back as clock?
+//
+// One 512-thread workgroup per CU (2 waves / SIMD, like the conv kernels).  Waves 0-3 ("matrix set") run the 3x3 kernel's
+// K-step diet: 8 MFMA 32x32x16 f16 on conv-like operands + 4 ds_read_b128 + 2 L2-resident 1 KiB weight-record loads.
+// Waves 4-7 ("memory set") run the tail's second half as pure traffic: every lane reads 64 contiguous bytes of a 2 KiB
+// row (four 16-byte pieces = the shortcut pattern), and writes 64 bytes of another 2 KiB row (the output pattern), over
+// buffers far larger than the 256 MB Infinity Cache.
+//   mode 1: matrix set only   mode 2: memory set only   mode 3: both, sized so that each would take the same time alone
+//   mode 4: both sets do BOTH jobs back to back (phase-locked: what 2 co-resident workgroups of the shipped kernel do)
+//   hipcc --offload-arch=gfx950 -O3 scripts/phase_overlap_probe.hip -o scripts/phase_overlap_probe
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float float16v __attribute__((ext_vector_type(16)));
+
+struct Args {
+    const _Float16* wts;        // [>= 256 waves-worth] weight records, L2 resident
+    const _Float16* pix;        // 64 KiB of post-ReLU-like pixels, copied to LDS
+    const unsigned char* rd;    // shortcut-like source
+    unsigned char* wr;          // output-like sink
+    float* sink;
+    unsigned long long* lat;    // [3]: summed issue cycles, summed return cycles, loads (latency job)
+    int mat_iters;              // K-steps per matrix wave
+    int mem_iters;              // 4 KiB read + 4 KiB written per memory wave and iteration
+    int mode;
+    int mem_order;              // 0 quarter order (shipped), 2 coalesced
+    int variant;                // matrix job: 0 full diet, 1 no weight-record loads in the loop, 2 neither weight loads nor LDS reads
+};
+
+template <int VAR, int D = 4>
+__device__ __forceinline__ float matrix_job_v(const Args& a, unsigned char* smem, int w, int lane, int iters) {
+    float16v acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.wts), 0, 1 << 22, 0x00020000);
+    const unsigned char* fb = smem + (lane & 31) * 144 + (lane >> 5) * 16 + w * 32 * 144;
+    half8 wf[D][2], pf[2][4];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        wf[d][0] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16, (w * 64 + d) * 2048, 0));
+        wf[d][1] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16 + 1024, (w * 64 + d) * 2048, 0));
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pf[0][i] = pf[1][i] = *reinterpret_cast<const half8*>(fb + i * 32 * 144);
+    for (int it = 0; it < iters; it += D) {
+#pragma unroll
+        for (int t = 0; t < D; ++t) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (VAR < 2) pf[(t + 1) & 1][i] = *reinterpret_cast<const half8*>(fb + i * 32 * 144 + ((t + 1) & 3) * 32);
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    acc[blk * 4 + i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[t][blk], pf[t & 1][i], acc[blk * 4 + i], 0, 0, 0);
+            const int so = (w * 64 + ((it + t + D) & 63)) * 2048;
+            if (VAR < 1) {
+                wf[t][0] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16, so, 0));
+                wf[t][1] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16 + 1024, so, 0));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][7];
+    return s;
+}
+
+// one weight-record load at a time: cycles spent ISSUING it (s_memtime around the instruction) and cycles until it has returned
+__device__ __forceinline__ float latency_job(const Args& a, int w, int lane, int iters, unsigned long long* out) {
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.wts), 0, 1 << 22, 0x00020000);
+    unsigned long long t_issue = 0, t_ret = 0;
+    float s = 0.f;
+    for (int it = 0; it < iters; ++it) {
+        const int so = (w * 64 + (it & 63)) * 2048;
+        const unsigned long long t0 = __builtin_readcyclecounter();
+        half8 v = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16, so, 0));
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long t1 = __builtin_readcyclecounter();
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(v) :: "memory");
+        const unsigned long long t2 = __builtin_readcyclecounter();
+        t_issue += t1 - t0; t_ret += t2 - t0;
+        s += (float)v[0];
+        __builtin_amdgcn_s_sleep(8);
+    }
+    if (lane == 0) { atomicAdd(out, t_issue); atomicAdd(out + 1, t_ret); atomicAdd(out + 2, (unsigned long long)iters); }
+    return s;
+}
+
+__device__ __forceinline__ float matrix_job(const Args& a, unsigned char* smem, int w, int lane, int iters) {
+    if (a.variant == 9) return latency_job(a, w, lane, iters, a.lat);
+    if (a.variant == 1) return matrix_job_v<1>(a, smem, w, lane, iters);
+    if (a.variant == 2) return matrix_job_v<2>(a, smem, w, lane, iters);
+    if (a.variant == 3) return matrix_job_v<0, 8>(a, smem, w, lane, iters);
+    return matrix_job_v<0>(a, smem, w, lane, iters);
+}
+
+// The tail's second half as pure traffic.  Tiles of 128 rows x 2 KiB (= 128 pixels x 1024 channels fp16); a workgroup slot takes
+// tiles slot, slot + nslots, ...; wave w owns the 512-byte column window w of all 128 rows = four 128-byte chunks; per chunk and
+// "quarter" q the wave reads piece q (16 B) of every lane's 64 bytes for the four 32-row blocks (lane = row (l & 31), half (l >> 5))
+// - the shipped kernel's shortcut order - two quarters in flight, and writes the chunk (four 16-byte stores per lane and row block).
+// ORDER 1: the four pieces of a lane's 64 bytes back to back, row block by row block.
+template <int ORDER>
+__device__ __forceinline__ float memory_job(const Args& a, int slot, int nslots, int w, int lane, int ntiles) {
+    float s = 0.f;
+    half8 v[2][4];
+    for (int t = slot; t < ntiles; t += nslots) {
+        const unsigned char* rb = a.rd + (size_t)t * 262144 + (size_t)(lane & 31) * 2048 + w * 512 + (lane >> 5) * 64;
+        unsigned char* wb = a.wr + (size_t)t * 262144 + (size_t)(lane & 31) * 2048 + w * 512 + (lane >> 5) * 64;
+        auto ld = [&](int set, int g) {          // g = chunk * 4 + quarter (ORDER 0) | chunk * 4 + row block (ORDER 1)
+            const int c = g >> 2, q = g & 3;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                v[set][i] = ORDER == 0 ? *reinterpret_cast<const half8*>(rb + c * 128 + (size_t)i * 65536 + q * 16)
+                                       : *reinterpret_cast<const half8*>(rb + c * 128 + (size_t)q * 65536 + i * 16);
+        };
+        ld(0, 0);
+#pragma unroll 1
+        for (int c = 0; c < 4; ++c) {
+            half8 o[4][4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int g = c * 4 + q;
+                if (g + 1 < 16) ld((g + 1) & 1, g + 1);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    half8 x = v[g & 1][i];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) x[e] = x[e] > (_Float16)0 ? x[e] : (_Float16)0;
+                    if (ORDER == 0) o[i][q] = x; else o[q][i] = x;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) *reinterpret_cast<half8*>(wb + c * 128 + (size_t)i * 65536 + q * 16) = o[i][q];
+        }
+    }
+    return s;
+}
+
+// ORDER 2 of the same traffic: fully coalesced - an instruction covers 8 rows x the wave's 128-byte chunk (lane l: row l >> 3 of the
+// group, piece l & 7), sixteen instructions per chunk, eight in flight; what an LDS-staged shortcut / output path would issue.
+__device__ __forceinline__ float memory_job_coalesced(const Args& a, int slot, int nslots, int w, int lane, int ntiles) {
+    half8 v[2][8];
+    for (int t = slot; t < ntiles; t += nslots) {
+        const unsigned char* rb = a.rd + (size_t)t * 262144 + (size_t)(lane >> 3) * 2048 + w * 512 + (lane & 7) * 16;
+        unsigned char* wb = a.wr + (size_t)t * 262144 + (size_t)(lane >> 3) * 2048 + w * 512 + (lane & 7) * 16;
+        auto ld = [&](int set, int g) {          // g = chunk * 2 + half: rows half * 64 + j * 8 + (l >> 3)
+            const int c = g >> 1, hf = g & 1;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[set][j] = *reinterpret_cast<const half8*>(rb + c * 128 + (size_t)(hf * 64 + j * 8) * 2048);
+        };
+        ld(0, 0);
+#pragma unroll 1
+        for (int g = 0; g < 8; ++g) {
+            if (g + 1 < 8) ld((g + 1) & 1, g + 1);
+            const int c = g >> 1, hf = g & 1;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                half8 x = v[g & 1][j];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] = x[e] > (_Float16)0 ? x[e] : (_Float16)0;
+                *reinterpret_cast<half8*>(wb + c * 128 + (size_t)(hf * 64 + j * 8) * 2048) = x;
+            }
+        }
+    }
+    return 0.f;
+}
+
+__global__ __launch_bounds__(512, 2) void probe(Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < 4096; i += 512) reinterpret_cast<half8*>(smem)[i] = reinterpret_cast<const half8*>(a.pix)[i];
+    __syncthreads();
+    float s = 0.f;
+    const int w = wave & 3;
+    const int ntiles = a.mem_iters;
+    if (a.mode == 4) {
+        // phase-locked: all 8 waves do half of the matrix work, then half of the memory work (two tile streams per CU)
+        s += matrix_job(a, smem, w, lane, a.mat_iters / 2);
+        s += memory_job<0>(a, blockIdx.x * 2 + (wave >> 2), 512, w, lane, ntiles);
+    } else if (a.mode == 5) {
+        s += matrix_job(a, smem, w, lane, a.mat_iters / 2);       // 2 matrix waves per SIMD, same total work as mode 1
+    } else if (a.mode == 6) {
+        s += memory_job<0>(a, blockIdx.x * 2 + (wave >> 2), 512, w, lane, ntiles);   // 8 memory waves per CU
+    } else if (a.mode == 7) {
+        s += memory_job<1>(a, blockIdx.x * 2 + (wave >> 2), 512, w, lane, ntiles);   // same, pieces back to back
+    } else if (wave < 4) {
+        if (a.mode & 1) s += matrix_job(a, smem, w, lane, a.mat_iters);
+    } else {
+        if (a.mode & 2) s += a.mem_order == 2 ? memory_job_coalesced(a, blockIdx.x, 256, w, lane, ntiles) : memory_job<0>(a, blockIdx.x, 256, w, lane, ntiles);
+    }
+    if (s == 12345.678f) a.sink[0] = s;
+}
+
+static float run(Args a, int reps) {
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float best = 1e30f;
+    for (int r = 0; r < reps; ++r) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(probe, dim3(256), dim3(512), 72 * 1024, 0, a);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        if (r > 0 && ms < best) best = ms;
+    }
+    return best;
+}
+
+int main(int argc, char** argv) {
+    const int ntiles = argc > 1 ? atoi(argv[1]) : 8192;        // 8192 tiles x 256 KiB = 2 GiB read + 2 GiB written (res4 at batch 32: 800)
+    const size_t span = (size_t)ntiles * 262144;
+    std::vector<_Float16> hw(1 << 21), hp(32768);
+    srand(1);
+    auto nrm = [] { float s = 0; for (int i = 0; i < 12; ++i) s += rand() / (float)RAND_MAX; return s - 6.f; };
+    for (auto& x : hw) x = (_Float16)(nrm() / 48.f);
+    for (auto& x : hp) { float v = nrm(); x = (_Float16)(v > 0 ? v : 0); }
+    Args a{};
+    _Float16 *dw, *dp; unsigned char *rd, *wr; float* sink;
+    hipMalloc(&dw, hw.size() * 2); hipMemcpy(dw, hw.data(), hw.size() * 2, hipMemcpyHostToDevice);
+    hipMalloc(&dp, hp.size() * 2); hipMemcpy(dp, hp.data(), hp.size() * 2, hipMemcpyHostToDevice);
+    hipMalloc(&rd, span); hipMalloc(&wr, span); hipMalloc(&sink, 4);
+    hipMemset(wr, 0, span);
+    {   // shortcut-like data: post-ReLU halfs
+        std::vector<_Float16> blk(1 << 22);
+        for (auto& x : blk) { float v = nrm(); x = (_Float16)(v > 0 ? v : 0); }
+        for (size_t o = 0; o < span; o += blk.size() * 2) hipMemcpy(rd + o, blk.data(), std::min(blk.size() * 2, span - o), hipMemcpyHostToDevice);
+    }
+    hipFuncSetAttribute((const void*)probe, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
+    a.wts = dw; a.pix = dp; a.rd = rd; a.wr = wr; a.sink = sink;
+    a.mem_iters = ntiles;
+    const double mem_bytes = 2.0 * span;
+    a.mat_iters = 4096; a.mode = 1;
+    float t_mat = run(a, 4);
+    a.mode = 2;
+    const float t_mem = run(a, 4);
+    a.mode = 6;
+    const float t_mem8 = run(a, 4);
+    a.mode = 7;
+    const float t_mem8b = run(a, 4);
+    printf("memory set alone, 4 waves / CU : %.3f ms  %6.2f TB/s read+write (%.0f MB each way)\n", t_mem, mem_bytes / t_mem / 1e9, mem_bytes / 2e6);
+    printf("memory job on all 8 waves / CU : %.3f ms  %6.2f TB/s   (pieces back to back instead of quarter order: %.3f ms  %6.2f TB/s)\n", t_mem8,
+           mem_bytes / t_mem8 / 1e9, t_mem8b, mem_bytes / t_mem8b / 1e9);
+    for (int pass = 0; pass < 4; ++pass) {
+        a.variant = pass;
+        printf("== matrix job variant %d (0 full diet, 1 no weight-record loads, 2 MFMA only, 3 full diet with weight records 8 K-steps ahead)\n", pass);
+        // pass 0: the matrix job sized to the 4-wave memory job's time; pass 1: to the 8-wave memory job's time (the tail's real ratio is ~1:1)
+        const float target = t_mem;
+        a.mat_iters = 4096; a.mode = 1;
+        t_mat = run(a, 3);
+        a.mat_iters = (int)(4096.0 * target / t_mat) / 8 * 8;
+        t_mat = run(a, 4);
+        const double mat_flop = 2.0 * 32 * 32 * 16 * 8.0 * a.mat_iters * 4 * 256;
+        printf("-- matrix job sized to %.3f ms: %d K-steps (8 MFMA + 4 ds_read_b128 + 2 weight records) per wave\n", target, a.mat_iters);
+        printf("matrix set alone, 1 wave / SIMD: %.3f ms  %7.0f TFLOP/s\n", t_mat, mat_flop / t_mat / 1e9);
+        a.mode = 5;
+        const float t_mat8 = run(a, 4);
+        printf("same work on 2 waves / SIMD    : %.3f ms  %7.0f TFLOP/s\n", t_mat8, mat_flop / t_mat8 / 1e9);
+        a.mode = 3;
+        const float t_both = run(a, 4);
+        printf("matrix set + memory set at once: %.3f ms  = %.2f x max(alone), %.2f x sum(alone)   -> %7.0f TFLOP/s and %.2f TB/s concurrently\n", t_both,
+               t_both / std::max(t_mat, t_mem), t_both / (t_mat + t_mem), mat_flop / t_both / 1e9, mem_bytes / t_both / 1e9);
+        a.mode = 4;
+        const float t_lock = run(a, 4);
+        printf("phase-locked (all 8 waves: matrix half, then memory half; same total work): %.3f ms  = %.2f x (2-wave matrix + 8-wave memory alone)\n", t_lock,
+               t_lock / (t_mat8 + t_mem8));
+    }
+    a.mem_order = 2; a.mode = 2;
+    const float t_memc = run(a, 4);
+    printf("== memory set with COALESCED accesses (8 rows x 128 B per instruction): alone %.3f ms  %6.2f TB/s\n", t_memc, mem_bytes / t_memc / 1e9);
+    for (int pass = 0; pass < 4; pass += 3) {
+        a.variant = pass;
+        a.mat_iters = 4096; a.mode = 1;
+        t_mat = run(a, 3);
+        a.mat_iters = (int)(4096.0 * t_memc / t_mat) / 8 * 8;
+        t_mat = run(a, 4);
+        const double mat_flop = 2.0 * 32 * 32 * 16 * 8.0 * a.mat_iters * 4 * 256;
+        a.mode = 3;
+        const float t_both = run(a, 4);
+        printf("matrix variant %d alone %.3f ms (%7.0f TFLOP/s); + coalesced memory set at once: %.3f ms = %.2f x sum(alone) -> %7.0f TFLOP/s and %.2f TB/s\n", pass, t_mat,
+               mat_flop / t_mat / 1e9, t_both, t_both / (t_mat + t_memc), mat_flop / t_both / 1e9, mem_bytes / t_both / 1e9);
+    }
+    {   // L2-hit weight-record load: issue and return time seen by waves 0-3, alone and beside the memory set
+        unsigned long long* lat; hipMalloc(&lat, 24);
+        a.lat = lat; a.variant = 9; a.mem_order = 0; a.mat_iters = 2000;
+        for (int mode = 1; mode <= 3; mode += 2) {
+            unsigned long long h[3];
+            a.mode = mode;
+            for (int order = 0; order <= (mode == 3 ? 2 : 0); order += 2) {
+                a.mem_order = order;
+                hipMemset(lat, 0, 24);
+                hipLaunchKernelGGL(probe, dim3(256), dim3(512), 72 * 1024, 0, a);
+                hipMemcpy(h, lat, 24, hipMemcpyDeviceToHost);
+                printf("weight-record load (1 KiB, L2 hit), %s: issue %.0f cycles, issue -> returned %.0f cycles (s_memtime ticks, %llu loads)\n",
+                       mode == 1 ? "memory set idle" : order ? "beside the coalesced memory set" : "beside the quarter-order memory set",
+                       (double)h[0] / h[2], (double)h[1] / h[2], h[2]);
+            }
+        }
+    }
+    return 0;
+}

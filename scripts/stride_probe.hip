@@ -72,6 +72,21 @@ __global__ __launch_bounds__(256) void sweep_lane64(const char* src, float* sink
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
                     acc += *reinterpret_cast<const float4v*>(src + base + (size_t)(i * 32 + (lane & 31)) * row_bytes + c * 128 + (lane >> 5) * 64 + j * 16);
+        } else if (MODE == 3) {   // quarter order, but a quarter = one 32-byte sector per row (lane pair l, l + 32 adjacent)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    acc += *reinterpret_cast<const float4v*>(src + base + (size_t)(i * 32 + (lane & 31)) * row_bytes + c * 128 + j * 32 + (lane >> 5) * 16);
+        } else if (MODE == 4) {   // quarter order behind a one-dword-per-line touch of the chunk's 128 lines
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                acc[0] += *reinterpret_cast<const float*>(src + base + (size_t)(i * 64 + lane) * row_bytes + c * 128);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    acc += *reinterpret_cast<const float4v*>(src + base + (size_t)(i * 32 + (lane & 31)) * row_bytes + c * 128 + (lane >> 5) * 64 + j * 16);
         } else {
 #pragma unroll
             for (int i = 0; i < 16; ++i)
@@ -108,7 +123,7 @@ int main() {
             }
         }
     }
-    for (int mode = 0; mode < 3; ++mode) {
+    for (int mode = 0; mode < 5; ++mode) {
         const int rb = 2048;
         const int blocks = (int)(bytes / (128ull * rb));
         float best = 1e9;
@@ -117,11 +132,13 @@ int main() {
             if (mode == 0) hipLaunchKernelGGL(sweep_lane64<0>, dim3(blocks), dim3(256), 0, 0, src, sink, rb);
             if (mode == 1) hipLaunchKernelGGL(sweep_lane64<1>, dim3(blocks), dim3(256), 0, 0, src, sink, rb);
             if (mode == 2) hipLaunchKernelGGL(sweep_lane64<2>, dim3(blocks), dim3(256), 0, 0, src, sink, rb);
+            if (mode == 3) hipLaunchKernelGGL(sweep_lane64<3>, dim3(blocks), dim3(256), 0, 0, src, sink, rb);
+            if (mode == 4) hipLaunchKernelGGL(sweep_lane64<4>, dim3(blocks), dim3(256), 0, 0, src, sink, rb);
             hipEventRecord(e1); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1);
             if (ms < best) best = ms;
         }
-        printf("lane-owns-64-bytes pattern, mode %d (0 = pieces back to back, 1 = quarter order, 2 = coalesced): %7.3f ms  %6.0f GB/s\n", mode, best,
+        printf("lane-owns-64-bytes pattern, mode %d (0 = pieces back to back, 1 = quarter order, 2 = coalesced, 3 = quarter order by 32-byte sectors, 4 = quarter order behind a line touch): %7.3f ms  %6.0f GB/s\n", mode, best,
                bytes / (best * 1e-3) / 1e9);
     }
     char* dst; hipMalloc(&dst, bytes);
