@@ -377,6 +377,9 @@ def main(argv=None):
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     dets, fused = out
+    from proben_amd.fusion import check_candidate_overflow
+    for d in dets:           # outside the timed region: a box head that ran out of candidate slots would have dropped detections
+        check_candidate_overflow(d)
     n_det = float(sum(d["counts"].float().mean() for d in dets)) / len(dets)
     if rank == 0:
         units = world * B * args.steps

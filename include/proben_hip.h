@@ -214,6 +214,9 @@ int pe_stem_conv7x7_maxpool_f16(const void* x, const void* w_packed, const float
  *   the per-class fast path: tiles of the suppression matrix between different classes are never computed),
  *   counts [B] rows used per image (NULL = n_max), valid [B,n_max] optional row mask.
  *   mode 0: coordinate trick (boxes + idx*(max+1)), mode 1: suppress only within equal idx ("vanilla").
+ *   Mode 0 is evaluated per class while every live coordinate of the image is >= 0 (then the bands cannot meet); an image
+ *   with a negative coordinate is compared all-pairs on the shifted boxes, so a box reaching below -1 suppresses - and is
+ *   suppressed by - the neighbouring class exactly as torchvision's trick does.
  *   out_keep [B,max_out] input-row indices in score-descending order (ties: lower index first),
  *   out_counts [B].  scratch: pe_nms_scratch_bytes(B, n_max) bytes of device memory.
  * ------------------------------------------------------------------------------------------- */

@@ -375,11 +375,7 @@ extern "C" int pe_bneck64_f16(const void* t1, const void* shortcut_src, const vo
     hipStream_t st = (hipStream_t)stream;
 #define PE_B64_LAUNCH(SC, NX)                                                                                                       \
     do {                                                                                                                            \
-        static bool done = false;                                                                                                   \
-        if (!done) {                                                                                                                \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bneck64_kernel<SC, NX>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES); \
-            done = true;                                                                                                            \
-        }                                                                                                                           \
+        PE_ENSURE_LDS((bneck64_kernel<SC, NX>), LDS_BYTES, "pe_bneck64_f16");                                                            \
         hipLaunchKernelGGL((bneck64_kernel<SC, NX>), grid, block, LDS_BYTES, st, a);                                               \
     } while (0)
     if (has_shortcut_conv && has_next) PE_B64_LAUNCH(true, true);

@@ -13,12 +13,23 @@ namespace pe {
 
 void set_error(const char* fmt, ...);
 
+// Opt a kernel in to `bytes` of dynamic LDS (> the 64 KiB default).  The attribute belongs to the (function, device) pair: it is
+// applied once per pair (not once per process under whichever device happened to be current), from any thread, and its status
+// is checked - on a part that cannot grant the request the launch path returns PE_ERR_HIP instead of failing at the launch.
+int ensure_dynamic_lds(const void* kernel, size_t bytes, const char* what);
+
 #define PE_CHECK_ARG(cond, ...)                  \
     do {                                         \
         if (!(cond)) {                           \
             pe::set_error(__VA_ARGS__);          \
             return PE_ERR_INVALID_ARG;           \
         }                                        \
+    } while (0)
+
+#define PE_ENSURE_LDS(kernel, bytes, name)                                                     \
+    do {                                                                                       \
+        const int st_ = pe::ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), bytes, name); \
+        if (st_ != PE_OK) return st_;                                                          \
     } while (0)
 
 #define PE_CHECK_LAUNCH(name)                                                      \

@@ -271,12 +271,7 @@ int launch(const ConvArgs& a0, hipStream_t st) {
     a.tiles_m = pe::ceil_div(a.M, BM);
     a.tiles_n = pe::ceil_div(a.Cout, BN);
     constexpr size_t lds = (size_t)2 * (BM + BN) * LDS_ROW * 2;
-    static bool attr_done = false;
-    if (!attr_done && lds > 64 * 1024) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, MODE>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
+    PE_ENSURE_LDS((conv_igemm_kernel<BM, BN, MODE>), lds, "pe_conv2d_nhwc_f16");
     hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, MODE>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds, st, a);
     PE_CHECK_LAUNCH("pe_conv2d_nhwc_f16");
     return PE_OK;

@@ -307,14 +307,7 @@ int launch3x3r(const Conv2Args& a0, hipStream_t st) {
     constexpr size_t stage_b = (size_t)(BM + 8 + 2 * BN) * ROW_B;
     constexpr size_t lds_b = stage_b > epi ? stage_b : epi;
     const dim3 grid(a.tiles_m * a.tiles_n), block(BM * 2);
-    if (lds_b > 64 * 1024) {
-        static bool done = false;
-        if (!done) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3rb_kernel<BM, BN>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
-            done = true;
-        }
-    }
+    PE_ENSURE_LDS((conv3x3rb_kernel<BM, BN>), lds_b, "pe_conv2d_nhwc_f16(3x3 row-reuse)");
     hipLaunchKernelGGL((conv3x3rb_kernel<BM, BN>), grid, block, lds_b, st, a);
     PE_CHECK_LAUNCH("pe_conv2d_nhwc_f16(3x3 row-reuse, B double-buffered)");
     return PE_OK;
@@ -444,12 +437,7 @@ int launch_big(const Conv2Args& a0, hipStream_t st) {
     a.tiles_m = pe::ceil_div(a.M, 256);
     a.tiles_n = pe::ceil_div(a.Cout, 256);
     constexpr size_t lds = (size_t)2 * 512 * ROW_B;  // 128 KiB (the epilogue's 65 KiB staging reuses it)
-    static bool done = false;
-    if (!done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_big_kernel<MODE>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        done = true;
-    }
+    PE_ENSURE_LDS((conv_big_kernel<MODE>), lds, "pe_conv2d_nhwc_f16(256x256)");
     hipLaunchKernelGGL((conv_big_kernel<MODE>), dim3(a.tiles_m * a.tiles_n), dim3(512), lds, st, a);
     PE_CHECK_LAUNCH("pe_conv2d_nhwc_f16(256x256)");
     return PE_OK;
@@ -463,14 +451,7 @@ int launch2(const Conv2Args& a0, hipStream_t st) {
     constexpr size_t stage = (size_t)(BM + BN) * ROW_B * STAGES;
     constexpr size_t epi = (size_t)64 * (BN + 4) * 4;
     constexpr size_t lds = stage > epi ? stage : epi;
-    if (lds > 64 * 1024) {
-        static bool done = false;
-        if (!done) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm2_kernel<BM, BN, MODE, STAGES>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            done = true;
-        }
-    }
+    PE_ENSURE_LDS((conv_igemm2_kernel<BM, BN, MODE, STAGES>), lds, "pe_conv2d_nhwc_f16(v2)");
     hipLaunchKernelGGL((conv_igemm2_kernel<BM, BN, MODE, STAGES>), dim3(a.tiles_m * a.tiles_n), dim3(BM * 2), lds, st, a);
     PE_CHECK_LAUNCH("pe_conv2d_nhwc_f16(v2)");
     return PE_OK;

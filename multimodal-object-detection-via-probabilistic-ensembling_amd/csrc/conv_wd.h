@@ -535,12 +535,7 @@ int launch_conv3x3_wd(pe::ConvWdArgs a, hipStream_t st) {
     size_t lds = (size_t)3 * a.nseg * (a.seg + 2) * SLAB_ROW_B + (size_t)64 * WM * WN * 16;
     if (HEAD == 1 && lds < 32768) lds = 32768;        // the partial head sums reuse the slab ring
     if (HEAD == 2 && lds < 128 * 528) lds = 128 * 528;  // so does the fp16 copy of t
-    static bool done = false;
-    if (!done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wd_kernel<WM, WN, TPX, DEPTH, ABL, HEAD>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        done = true;
-    }
+    PE_ENSURE_LDS((conv3x3_wd_kernel<WM, WN, TPX, DEPTH, ABL, HEAD>), lds, "conv3x3_wd");
     hipLaunchKernelGGL((conv3x3_wd_kernel<WM, WN, TPX, DEPTH, ABL, HEAD>), dim3(a.tiles_m * a.tiles_n), dim3(64 * WM * WN), lds, st, a);
     return PE_OK;
 }

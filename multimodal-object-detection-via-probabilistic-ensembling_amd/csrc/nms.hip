@@ -56,7 +56,7 @@ struct NmsArgs {
 __global__ __launch_bounds__(kSortThreads) void nms_sort_kernel(NmsArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);
-    __shared__ float red[kSortThreads / 64];
+    __shared__ float red[kSortThreads / 64], red_mn[kSortThreads / 64];
     __shared__ int cnt_s, seg_s;
     const int b = blockIdx.x, tid = threadIdx.x;
     const int n = a.counts ? min(a.counts[b], a.n_max) : a.n_max;
@@ -64,25 +64,36 @@ __global__ __launch_bounds__(kSortThreads) void nms_sort_kernel(NmsArgs a) {
     const float* bx = a.boxes + (size_t)b * a.n_max * 4;
     if (tid == 0) { cnt_s = 0; seg_s = 0; }
     __syncthreads();
-    float mx = -INFINITY;
+    // pass 1: extrema of the coordinates of the live rows.  max -> the coordinate trick's per-class offset; min decides whether
+    // the per-class organisation is legal for mode 0: boxes + idx * (max + 1) keeps classes apart only while every coordinate
+    // is >= 0 (a box with coordinates below -1 reaches into the previous class's band and torchvision's trick lets the two
+    // suppress each other).  Such an image ("generic") is handled as ONE segment with all pairs compared on the shifted boxes.
+    float mx = -INFINITY, mn = INFINITY;
+    for (int i = tid; i < n; i += kSortThreads) {
+        if (a.valid && !a.valid[(size_t)b * a.n_max + i]) continue;
+        const float lo = fminf(fminf(bx[i * 4], bx[i * 4 + 1]), fminf(bx[i * 4 + 2], bx[i * 4 + 3]));
+        const float hi = fmaxf(fmaxf(bx[i * 4], bx[i * 4 + 1]), fmaxf(bx[i * 4 + 2], bx[i * 4 + 3]));
+        mx = fmaxf(mx, hi); mn = fminf(mn, lo);
+    }
+    for (int o = 32; o > 0; o >>= 1) { mx = fmaxf(mx, __shfl_xor(mx, o)); mn = fminf(mn, __shfl_xor(mn, o)); }
+    if ((tid & 63) == 0) { red[tid >> 6] = mx; red_mn[tid >> 6] = mn; }
+    __syncthreads();
+    mx = red[0]; mn = red_mn[0];
+    for (int w = 1; w < kSortThreads / 64; ++w) { mx = fmaxf(mx, red[w]); mn = fminf(mn, red_mn[w]); }
+    const bool generic = a.mode == 0 && a.idxs && mn < 0.f;
+    // pass 2: keys
     int local_cnt = 0;
     for (int i = tid; i < a.n_pad; i += kSortThreads) {
         unsigned long long k = ~0ull;
         if (i < n && (!a.valid || a.valid[(size_t)b * a.n_max + i])) {
-            const unsigned long long c = a.idxs ? ((unsigned)a.idxs[(size_t)b * a.n_max + i] & 0x3FFFFu) : 0u;   // class: 18 bits
+            const unsigned long long c = (a.idxs && !generic) ? ((unsigned)a.idxs[(size_t)b * a.n_max + i] & 0x3FFFFu) : 0u;   // class: 18 bits
             k = (c << 46) | ((unsigned long long)ordered_desc(sc[i]) << 14) | (unsigned)i;                       // index: 14 bits (n_max <= 16384)
             ++local_cnt;
-            mx = fmaxf(mx, fmaxf(fmaxf(bx[i * 4], bx[i * 4 + 1]), fmaxf(bx[i * 4 + 2], bx[i * 4 + 3])));
         }
         keys[i] = k;
     }
     atomicAdd(&cnt_s, local_cnt);
-    // block max of coordinates (for the coordinate trick)
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-    if ((tid & 63) == 0) red[tid >> 6] = mx;
     __syncthreads();
-    mx = red[0];
-    for (int w = 1; w < kSortThreads / 64; ++w) mx = fmaxf(mx, red[w]);
     // bitonic sort ascending
     for (int k = 2; k <= a.n_pad; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
@@ -109,7 +120,7 @@ __global__ __launch_bounds__(kSortThreads) void nms_sort_kernel(NmsArgs a) {
         float* o = a.sboxes + ((size_t)b * a.n_max + p) * 4;
         o[0] = bx[i * 4] + off; o[1] = bx[i * 4 + 1] + off; o[2] = bx[i * 4 + 2] + off; o[3] = bx[i * 4 + 3] + off;
         a.sidx[(size_t)b * a.n_max + p] = i;
-        a.scls[(size_t)b * a.n_max + p] = c;
+        a.scls[(size_t)b * a.n_max + p] = generic ? 0 : c;   // generic: one segment, every pair compared on the shifted boxes
     }
     __syncthreads();
     if (tid == 0) a.nseg[b] = seg_s;
@@ -148,7 +159,8 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(NmsArgs a) {
     const int jn = min(64, nv - col0);
     for (int j = (col0 == row0 ? t + 1 : 0); j < jn; ++j) {
         if (col0 + j <= r) continue;
-        if (cc[j] != rc) continue;   // mode 1 by definition; mode 0: shifted apart by (max_coord + 1) per class -> IoU 0
+        if (cc[j] != rc) continue;   // mode 1 by definition; mode 0: shifted apart by (max_coord + 1) per class -> IoU 0 (images with
+                                     // negative coordinates carry class 0 everywhere here: nms_sort_kernel's "generic" case)
         const float w = fmaxf(0.f, fminf(x2, cb[j][2]) - fmaxf(x1, cb[j][0]));
         const float h = fmaxf(0.f, fminf(y2, cb[j][3]) - fmaxf(y1, cb[j][1]));
         const float inter = w * h;
@@ -318,15 +330,13 @@ extern "C" int pe_nms_batched(const float* boxes, const float* scores, const int
     a.seg_start = (int32_t*)carve((size_t)B * n_max * 4);
     a.out_keep = out_keep; a.out_counts = out_counts;
     const size_t lds = (size_t)a.n_pad * 8;
-    if (lds > 64 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nms_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    PE_ENSURE_LDS(nms_sort_kernel, lds + 256, "pe_nms_batched(sort)");   // + the kernel's static LDS
     hipLaunchKernelGGL(nms_sort_kernel, dim3(B), dim3(kSortThreads), lds, st, a);
     PE_CHECK_LAUNCH("pe_nms_batched(sort)");
     hipLaunchKernelGGL(nms_mask_kernel, dim3(a.words, a.words, B), dim3(64), 0, st, a);
     PE_CHECK_LAUNCH("pe_nms_batched(mask)");
     const size_t lds2 = std::max((size_t)a.n_pad * 8, (((size_t)n_max * 2 + 15) & ~(size_t)15) + (size_t)a.n_pad / 8 + 16);
-    if (lds2 + 256 > 64 * 1024)   // + the kernel's static LDS
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nms_scan_order_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+    PE_ENSURE_LDS(nms_scan_order_kernel, lds2 + 256, "pe_nms_batched(scan + order)");   // + the kernel's static LDS
     hipLaunchKernelGGL(nms_scan_order_kernel, dim3(B), dim3(kScanThreads), lds2, st, a);
     PE_CHECK_LAUNCH("pe_nms_batched(scan + order)");
     return PE_OK;

@@ -291,22 +291,28 @@ extern "C" int pe_rpn_select_topk(const float* const* level_heads_host, const in
     }
     a.num_slices = ns;
     static_assert(kSliceKeys % kA == 0, "slices are cut at cell boundaries");
-    constexpr size_t key_lds = ((size_t)kSliceKeys * sizeof(unsigned) + 15) / 16 * 16;
-    static bool lds_set = false;
-    if (!lds_set) {   // 64 KiB of keys + ~9 KiB of static LDS is beyond the default 64 KiB cap
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rpn_slice_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)key_lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rpn_select_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)key_lds);
-        lds_set = true;
-    }
+    // Dynamic LDS = the staged objectness keys, sized for what THIS call stages (a stage-2 merge and the from-memory route of
+    // a big level without scratch stage nothing): small pyramids keep their launches under the 64 KiB default.
+    auto key_bytes = [](int keys) { return ((size_t)keys * sizeof(unsigned) + 15) / 16 * 16; };
     const size_t need = (size_t)N * ns * kMaxTopk * sizeof(unsigned long long);
-    if (scratch && ns > 0 && ns < 64 && scratch_bytes >= need) {
+    const bool two_stage = scratch && ns > 0 && ns < 64 && scratch_bytes >= need;
+    size_t lds_slice = 0, lds_select = 0;
+    for (int l = 0; l < num_levels; ++l) {
+        const int tot = a.lv[l].H * a.lv[l].W * kA;
+        if (two_stage && a.lv[l].num_slices > 1) lds_slice = std::max(lds_slice, key_bytes(std::min(tot, kSliceKeys)));
+        else if (tot <= kSliceKeys) lds_select = std::max(lds_select, key_bytes(tot));
+    }
+    constexpr size_t kStaticLds = 10 * 1024;   // hist + cand + counters of either kernel (9.3 KiB), rounded up
+    if (two_stage) {
         a.slice_out = (unsigned long long*)scratch;
-        hipLaunchKernelGGL(rpn_slice_kernel, dim3(ns, N), dim3(kThreads), key_lds, (hipStream_t)stream, a);
+        PE_ENSURE_LDS(rpn_slice_kernel, lds_slice + kStaticLds, "pe_rpn_select_topk(slices)");
+        hipLaunchKernelGGL(rpn_slice_kernel, dim3(ns, N), dim3(kThreads), lds_slice, (hipStream_t)stream, a);
         PE_CHECK_LAUNCH("pe_rpn_select_topk(slices)");
     } else {
         a.slice_out = nullptr;
     }
-    hipLaunchKernelGGL(rpn_select_kernel, dim3(num_levels, N), dim3(kThreads), key_lds, (hipStream_t)stream, a);
+    PE_ENSURE_LDS(rpn_select_kernel, lds_select + kStaticLds, "pe_rpn_select_topk");
+    hipLaunchKernelGGL(rpn_select_kernel, dim3(num_levels, N), dim3(kThreads), lds_select, (hipStream_t)stream, a);
     PE_CHECK_LAUNCH("pe_rpn_select_topk");
     return PE_OK;
 }

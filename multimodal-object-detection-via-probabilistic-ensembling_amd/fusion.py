@@ -127,6 +127,9 @@ def fuse_detections(dets, score_fusion="probEn", box_fusion="v-avg", max_class=2
     import ctypes
     nd = len(dets)
     B, D = dets[0]["scores"].shape
+    # the box heads' candidate-cap bookkeeping travels with the result (no kernel here): check_candidate_overflow() looks
+    # at it at the consumer's first host synchronisation
+    overflow_src = [(d["cand_total"], d["cand_max"]) for d in dets if "cand_total" in d]
     K = dets[0]["prob_score"].shape[2]
     dev = dets[0]["scores"].device
     S = nd * D
@@ -158,8 +161,26 @@ def fuse_detections(dets, score_fusion="probEn", box_fusion="v-avg", max_class=2
         # arrays (score-descending), so late_fusion.fused_rows_device / comm.all_gather_fused_rows need no special case
         g = (torch.arange(B, device=dev).view(B, 1) * S + keep.clamp(0, S - 1).long()).view(-1)
         return {"boxes": ob[g], "scores": os_.float()[g], "classes": oc.float()[g], "counts": kcnt, "keep": keep,
-                "offsets": ooff, "stride": S, "in_counts": ocnt, "nms_route": True}
+                "offsets": ooff, "stride": S, "in_counts": ocnt, "nms_route": True, "cand_overflow_src": overflow_src}
     out = fuse_batch(ob, os_, op, ov, oc, ooff, score_fusion, box_fusion, max_rows=S, iou_thresh=iou_thresh,
                      row_counts=ocnt, passthrough=osingle)
     out["offsets"], out["stride"], out["in_counts"] = ooff, S, ocnt
+    out["cand_overflow_src"] = overflow_src
     return out
+
+
+def check_candidate_overflow(result):
+    """Raise if a box head met more (proposal, class) candidates above SCORE_THRESH_TEST than its NMS stage holds
+    (rcnn._roi_heads: cand_total > cand_max) - the device-to-device routes (forward_batch -> FramePairPipeline ->
+    fuse_detections) would otherwise lose those detections silently, in proposal order, where the reference keeps all.
+    `result`: a forward_batch dict or a fuse_detections dict.  Synchronises with the device: call it where the consumer
+    reads results anyway (GeneralizedRCNN.to_instances does the same check for the Instances route)."""
+    src = result.get("cand_overflow_src")
+    if src is None and "cand_total" in result:
+        src = [(result["cand_total"], result["cand_max"])]
+    for tot, cmax in src or []:
+        worst = int(tot.max())
+        if worst > cmax:
+            raise RuntimeError(f"box head: {worst} (proposal, class) candidates pass the score threshold on one image but the "
+                               f"NMS stage holds {cmax}: detections would be dropped in proposal order (the reference keeps all). "
+                               "Raise SCORE_THRESH_TEST or lower POST_NMS_TOPK_TEST.")

@@ -126,6 +126,7 @@ def fused_rows_device(fused, image_ids, valid_classes=(0, 1, 2, 5, 7, 16)):
     B = fused["counts"].numel()
     S = fused["stride"]
     dev = fused["scores"].device
+    F.check_candidate_overflow(fused)   # evaluation rows leave for the host / other ranks from here: the one sync point
     slot = torch.arange(S, device=dev).unsqueeze(0)                                  # [1,S]
     live = slot < fused["counts"].unsqueeze(1)                                       # [B,S]
     cls = fused["classes"].view(B, S).to(torch.int64)

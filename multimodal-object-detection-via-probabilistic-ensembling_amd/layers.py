@@ -47,7 +47,9 @@ def nms_batched_raw(boxes, scores, idxs, counts, valid, iou_threshold, mode, max
 def batched_nms(boxes, scores, idxs, iou_threshold):
     """Drop-in for detectron2.layers.batched_nms (layers/nms.py:20-37): boxes [N,4], scores [N],
     idxs [N] -> int64 keep indices sorted by score descending.  torchvision's dispatch rule is kept:
-    coordinate trick up to 20000 box elements on a GPU, one NMS per class beyond that."""
+    coordinate trick up to 20000 box elements on a GPU, one NMS per class beyond that.  Arbitrary boxes are fine: with
+    negative coordinates the trick's class bands can overlap and the kernel then compares all pairs like torchvision
+    (csrc/nms.hip, "generic" images)."""
     assert boxes.shape[-1] == 4
     _lib.require_cuda(boxes, scores, idxs)
     n = boxes.shape[0]

@@ -74,6 +74,9 @@ class PackedDetector:
         assert self.num_classes == ncls, (self.num_classes, ncls)
         self.convs = {}
         self.wd = {}   # name -> fragment-ordered copy of a 3x3 weight for the weights-direct kernel (csrc/conv_wd.h)
+        self.tails = {}            # block -> packed conv3 of a fused bottleneck tail      } filled by _pack_wd on a GPU; a host-packed
+        self.chains64 = {}         # stage -> fused 64-wide chain (res2)                  } object keeps them empty, so rcnn raises its
+        self.rpn_head_fused = None  # packed 15-row RPN head for the fused launch         } 'no CPU fallback' error, not AttributeError
         self._pack_backbone(sd, "backbone")
         if self.has_backbone_2:
             self._pack_backbone(sd, "backbone_2")

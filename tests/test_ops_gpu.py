@@ -472,6 +472,29 @@ def test_nms_per_class_fast_path_keeps_the_generic_contract(L):
     np.testing.assert_array_equal(keep[0, : int(cnt[0])].cpu().numpy(), want)
 
 
+def test_nms_coordinate_trick_with_negative_coordinates(L):
+    """torchvision's trick shifts class c by c * (max + 1): a box reaching below -1 overlaps the band of class c - 1 and the two
+    can suppress each other.  The per-class organisation of the kernels must not lose that: images with a negative
+    coordinate take the all-pairs route; images without stay per class; both in one batched call."""
+    from oracle import nms as O
+    g = torch.Generator().manual_seed(5)
+    n = 600
+    b = rand_boxes(g, n, span=80.0)
+    b[: n // 2] -= 200.0                      # half the boxes reach far below zero: into the band of the class below
+    s = torch.rand(n, generator=g)
+    c = torch.randint(0, 4, (n,), generator=g).int()
+    want = O.batched_nms_f32(b.numpy(), s.numpy(), c.numpy(), 0.3, mode="trick")
+    per_class = O.batched_nms_f32(b.numpy(), s.numpy(), c.numpy(), 0.3, mode="vanilla")
+    assert len(want) != len(per_class), "the case must actually contain cross-class suppression"
+    got = L.batched_nms(b.cuda(), s.cuda(), c.cuda(), 0.3).cpu().numpy()
+    np.testing.assert_array_equal(got, want)
+    b2 = torch.stack([b, b.clamp(min=0)])     # image 0 generic, image 1 per class
+    keep, cnt = L.nms_batched_raw(b2.cuda(), torch.stack([s, s]).cuda(), torch.stack([c, c]).cuda(), None, None, 0.3, 0, n)
+    np.testing.assert_array_equal(keep[0, : int(cnt[0])].cpu().numpy(), want)
+    np.testing.assert_array_equal(keep[1, : int(cnt[1])].cpu().numpy(),
+                                  O.batched_nms_f32(b2[1].numpy(), s.numpy(), c.numpy(), 0.3, mode="trick"))
+
+
 # ------------------------------------------------------------------------------------------------ RPN
 @pytest.mark.parametrize("two_stage", [False, True])
 def test_rpn_select_matches_oracle(two_stage):
