@@ -6,23 +6,30 @@ them on the GPU, evaluate with FLIREvaluator.
 """
 import json
 import os
+import sys
 
-from .. import get_cfg
+from .. import comm, get_cfg, launch
 from ..data import DatasetCatalog, register_coco_instances
 from ..evaluation import FLIREvaluator
-from ..late_fusion import apply_late_fusion_and_evaluate, read_j1
+from ..late_fusion import apply_late_fusion_and_evaluate, read_j1, shard_j1
 from ..opt import config_parser
 
 
 def main(cmd=None):
-    args = config_parser(cmd)
+    argv = list(cmd) if cmd is not None else sys.argv[1:]
+    args = config_parser(argv)
+    # --world-size N: the image list is cut into N contiguous blocks, every rank fuses its block on its own GPU and the
+    # evaluator gathers the fused rows to rank 0 (one tensor all-gather over RCCL)
+    launch.maybe_self_launch(args.world_size, argv, module="proben_amd.cli.demo_probEn", device=args.device)
+    rank, world, dev = launch.init_distributed(args.device, expect_world=args.world_size)
     names = [n for n in args.detectors.split(",") if n]
     assert 2 <= len(names) <= 3, "--detectors takes 2 or 3 names"
     files = [os.path.join(args.prediction_path, f"val_{n}_predictions.json") for n in names]
-    for i, f in enumerate(files):
-        print(f"detection file {i + 1}:", f)
+    if comm.is_main_process():
+        for i, f in enumerate(files):
+            print(f"detection file {i + 1}:", f)
+        os.makedirs(args.outfolder, exist_ok=True)
     val_json = os.path.join(args.dataset_path, "FLIR_thermal_RGBT_pairs_val.json")
-    os.makedirs(args.outfolder, exist_ok=True)
     register_coco_instances(args.dataset_name, {}, val_json, os.path.join(args.dataset_path, "thermal_8_bit"))
     DatasetCatalog.get(args.dataset_name)
     cfg = get_cfg()
@@ -31,13 +38,19 @@ def main(cmd=None):
     cfg.MODEL.ROI_HEADS.NUM_CLASSES = 3
     cfg.DATASETS.TEST = (args.dataset_name,)
     dets = [read_j1(f) for f in files]
+    mine = comm.shard_range(len(dets[-1]["image"]))
+    dets = [shard_j1(d, mine) for d in dets]
     with open(val_json) as f:
         hw = {im["id"]: (im["height"], im["width"]) for im in json.load(f)["images"]}
-    ev = FLIREvaluator(args.dataset_name, cfg, False, output_dir=args.outfolder, save_eval=True,
+    main_rank = comm.is_main_process()
+    ev = FLIREvaluator(args.dataset_name, cfg, world > 1, output_dir=args.outfolder if main_rank else None, save_eval=main_rank,
                        out_eval_path=os.path.join(args.outfolder, "FLIR_probEn_eval.json"))
     res = apply_late_fusion_and_evaluate(cfg, ev, dets[0], dets[1], [args.score_fusion, args.box_fusion],
-                                         det_3=dets[2] if len(dets) > 2 else "", image_hw=hw, device=args.device)
-    print(json.dumps(res, indent=1))
+                                         det_3=dets[2] if len(dets) > 2 else "", image_hw=hw, device=str(dev))
+    if main_rank:
+        print(json.dumps(res, indent=1))
+    if world > 1:
+        launch.shutdown()
     return res
 
 

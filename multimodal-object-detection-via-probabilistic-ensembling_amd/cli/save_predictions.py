@@ -10,7 +10,9 @@ import os
 
 import numpy as np
 
-from .. import comm, get_cfg
+import sys
+
+from .. import comm, get_cfg, launch
 from ..data import cv2_linear_resize_u8, read_image
 from ..late_fusion import predictions_to_j1, write_j1
 from ..opt import config_parser
@@ -58,13 +60,17 @@ def load_input(method, rgb_file, thermal_file):
 
 def main(cmd=None):
     from ..predictor import DefaultPredictor
-    args = config_parser(cmd)
+    argv = list(cmd) if cmd is not None else sys.argv[1:]
+    args = config_parser(argv)
+    launch.maybe_self_launch(args.world_size, argv, module="proben_amd.cli.save_predictions", device=args.device)
+    rank, world, dev = launch.init_distributed(args.device, expect_world=args.world_size)
     with open(os.path.join(args.dataset_path, "FLIR_thermal_RGBT_pairs_val.json")) as f:
         data = json.load(f)
     cfg = build_cfg(args)
+    cfg.MODEL.DEVICE = dev.type      # "cuda" = this rank's current device (LOCAL_RANK); "cpu" raises: no CPU detector in the product
     predictor = DefaultPredictor(cfg)
     images = data["images"]
-    idx = list(comm.shard_range(len(images)))
+    idx = list(comm.shard_range(len(images)))     # InferenceSampler: this rank's contiguous block
     names, ids, insts = [], [], []
     for b0 in range(0, len(idx), args.batch):
         chunk = [images[i] for i in idx[b0:b0 + args.batch]]
@@ -77,13 +83,17 @@ def main(cmd=None):
             ids.append(im["id"])
         insts += [o["instances"] for o in predictor.predict_batch(batch)]
     pred = predictions_to_j1(names, ids, insts)
-    os.makedirs(args.prediction_path or args.outfolder, exist_ok=True)
-    gathered = comm.gather(pred, dst=0)
+    out = os.path.join(args.prediction_path or args.outfolder, "val_" + args.fusion_method + "_predictions.json")
     if comm.is_main_process():
-        merged = {k: sum((g[k] for g in gathered), []) for k in pred}
-        out = os.path.join(args.prediction_path or args.outfolder, "val_" + args.fusion_method + "_predictions.json")
+        os.makedirs(os.path.dirname(out) or ".", exist_ok=True)
+    gathered = comm.gather(pred, dst=0)           # ragged per-image lists (logits, probs, vars): pickled, over the gloo side group
+    if comm.is_main_process():
+        merged = {k: sum((g[k] for g in gathered), []) for k in pred}      # rank order == dataset order
         write_j1(out, merged)
         print("out file:", out)
+    if world > 1:
+        launch.shutdown()
+    return out
 
 
 if __name__ == "__main__":

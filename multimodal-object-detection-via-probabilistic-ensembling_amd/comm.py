@@ -9,10 +9,26 @@ over RCCL/xGMI for CUDA tensors (backend "nccl") or gloo for CPU tensors (tests)
 ORDER so the row order equals the single-GPU order (InferenceSampler shards are contiguous).
 The payload is tiny (<= 3 MB per 1000 images): one latency-bound call, no bucketing.
 """
-import pickle
+import functools
 
 import torch
 import torch.distributed as dist
+
+_DEVICE = None   # the rank's device for tensor collectives (launch.init_distributed sets it); None = where the tensor lives
+
+
+def set_device(device):
+    global _DEVICE
+    _DEVICE = torch.device(device)
+
+
+@functools.lru_cache()
+def _object_group():
+    """Pickled host objects go over gloo (utils/comm.py:36-48 `_get_global_gloo_group`): with the NCCL/RCCL backend the
+    object collectives would stage every pickle through device memory."""
+    if dist.get_backend() == "nccl":
+        return dist.new_group(backend="gloo")
+    return dist.group.WORLD
 
 
 def get_world_size():
@@ -79,7 +95,7 @@ def gather(data, dst=0, group=None):
     if world == 1:
         return [data]
     out = [None] * world if get_rank() == dst else None
-    dist.gather_object(data, out, dst=dst, group=group)
+    dist.gather_object(data, out, dst=dst, group=group or _object_group())
     return out if get_rank() == dst else []
 
 
@@ -88,5 +104,16 @@ def all_gather(data, group=None):
     if world == 1:
         return [data]
     out = [None] * world
-    dist.all_gather_object(out, data, group=group)
+    dist.all_gather_object(out, data, group=group or _object_group())
     return out
+
+
+def gather_rows(rows):
+    """Evaluation rows of this rank ([n, C] tensor or array, any n) -> the rows of ALL ranks in rank order, on the host.
+    The payload crosses ranks as ONE padded tensor all-gather on the rank's device (RCCL over xGMI for CUDA ranks) - the
+    reference pickles per-image dict lists through gloo (evaluation/FLIR_evaluation.py:124-131)."""
+    t = torch.as_tensor(rows)
+    if get_world_size() == 1:
+        return t.cpu()
+    dev = _DEVICE if _DEVICE is not None else t.device
+    return all_gather_rows(t.to(dev).contiguous()).cpu()

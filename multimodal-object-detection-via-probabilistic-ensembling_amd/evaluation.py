@@ -281,12 +281,20 @@ class FLIREvaluator:
                 {"image_id": int(r[0]), "category_id": int(r[6]), "bbox": [r[1], r[2], r[3], r[4]], "score": float(r[5])}]})
 
     def evaluate(self, out_eval_path=""):
-        if self._distributed:
+        if self._distributed and comm.get_world_size() > 1:
+            # The reference gathers pickled per-image dict lists to rank 0 (FLIR_evaluation.py:124-131, comm.gather over gloo).
+            # Here a rank's predictions are [n, 7] float64 rows (image_id, x, y, w, h, score, category_id) - exact images of
+            # the float32 detector outputs - and ONE padded all-gather on the rank's device moves them (RCCL over xGMI);
+            # InferenceSampler shards are contiguous, so rank order IS dataset order and the table rank 0 evaluates is the
+            # single-process table, bit for bit.
             comm.synchronize()
-            preds = comm.gather(self._predictions, dst=0)
-            self._predictions = list(itertools.chain(*preds))
+            mine = [[r["image_id"], *r["bbox"], r["score"], r["category_id"]] for p in self._predictions for r in p.get("instances", [])]
+            rows = comm.gather_rows(torch.tensor(mine, dtype=torch.float64).reshape(-1, 7))
+            seen = comm.gather_rows(torch.tensor([[float(len(self._predictions))]], dtype=torch.float64))
             if not comm.is_main_process():
                 return {}
+            coco = [{"image_id": int(r[0]), "category_id": int(r[6]), "bbox": [r[1], r[2], r[3], r[4]], "score": r[5]} for r in rows.tolist()]
+            self._predictions = [{"image_id": -1, "instances": coco}] if int(seen.sum().item()) > 0 else []
         if len(self._predictions) == 0:
             self._logger.warning("[FLIREvaluator] Did not receive valid predictions.")
             return {}

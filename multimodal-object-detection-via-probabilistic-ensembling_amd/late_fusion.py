@@ -52,6 +52,12 @@ def read_j1(path):
     return d
 
 
+def shard_j1(det, index_range):
+    """The slice of a prediction dict one rank works on (contiguous InferenceSampler block: rank order == image order)."""
+    lo, hi = (index_range.start, index_range.stop) if len(index_range) else (0, 0)
+    return {k: v[lo:hi] for k, v in det.items()}
+
+
 def _info(det, i):
     return {"img_name": det["image"][i], "bbox": det["boxes"][i], "score": det["scores"][i], "class": det["classes"][i],
             "class_logits": det["class_logits"][i], "prob": det["probs"][i], "vars": det["vars"][i]}

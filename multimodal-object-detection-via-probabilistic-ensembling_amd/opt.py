@@ -16,7 +16,8 @@ def config_parser(cmd=None):
     p.add_argument("--box_fusion", type=str, default="v-avg", choices=["avg", "s-avg", "v-avg", "argmax"], help="Which fusion method to use?")
     p.add_argument("--device", type=str, default="cuda")
     p.add_argument("--batch", type=int, default=16)
-    p.add_argument("--world-size", type=int, default=1)
+    p.add_argument("--world-size", type=int, default=1,
+                   help="ranks (one per GPU) the dataset is sharded over; > 1 re-launches the driver under torch.distributed.run (launch.py)")
     p.add_argument("--detectors", type=str, default="thermal_only,early_fusion,middle_fusion",
                    help="comma separated prediction files to fuse, in order (val_<name>_predictions.json)")
     return p.parse_args(cmd) if cmd is not None else p.parse_args()

@@ -1,0 +1,100 @@
+"""VERDICT r02 item 3 on hardware: `python -m proben_amd.cli.<driver> --world-size 2` with the REAL detectors.
+Two devices visible -> ranks over RCCL ("nccl"), one per GPU.  One device visible -> (a) the drivers must refuse to fake two
+ranks, and (b) the same sharded code path runs with PROBEN_DIST_BACKEND=gloo, where the two ranks share the GPU and only the
+collectives differ (host tensors instead of RCCL) - the detector, the shard rule, the row tables, the rank-0 evaluation and
+writers are the ones a 2-GPU run uses.  Either way the gathered result must equal the single-rank result bit for bit."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _env(two_devices):
+    import proben_amd  # noqa: F401
+    from proben_amd import launch
+    env = launch.launch_env()
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "PROBEN_DIST_BACKEND"):
+        env.pop(k, None)
+    if not two_devices:
+        env["PROBEN_DIST_BACKEND"] = "gloo"
+    return env
+
+
+def _cli(module, args, env, expect_ok=True):
+    p = subprocess.run([sys.executable, "-m", "proben_amd.cli." + module] + args, capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
+    if expect_ok:
+        assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    return p
+
+
+def test_world_size_2_equals_world_size_1_on_the_flir_drivers(tmp_path):
+    import torch
+    from test_boundary_gpu import _write_flir
+    two = torch.cuda.device_count() >= 2
+    root = tmp_path / "val"
+    _write_flir(root, 7, 256, 320)
+    if not two:     # refusal path: no override, one device, two ranks requested
+        env = _env(True)
+        p = _cli("demo_mAP_FLIR", ["--dataset_path", str(root), "--fusion_method", "thermal_only", "--world-size", "2"], env, expect_ok=False)
+        assert p.returncode != 0 and "only 1 GPU" in (p.stdout + p.stderr)
+    env = _env(two)
+    # demo_mAP_FLIR: detector -> sharded loader -> row all-gather -> rank-0 COCOeval
+    res = {}
+    for world in (1, 2):
+        out = tmp_path / f"map{world}"
+        _cli("demo_mAP_FLIR", ["--dataset_path", str(root), "--fusion_method", "thermal_only", "--outfolder", str(out),
+                               "--dataset_name", f"flir_w{world}", "--world-size", str(world)], env)
+        res[world] = (json.load(open(out / "FLIR_mAP_results.json")), json.load(open(out / "coco_instances_results.json")))
+    assert res[2][0]["world_size"] == 2
+    assert res[1][1] == res[2][1] and len(res[1][1]) > 20
+    assert res[1][0]["results"] == res[2][0]["results"]
+    # save_predictions (two methods) -> demo_probEn on the device route, sharded over the ranks
+    pred = {}
+    for world in (1, 2):
+        pdir = tmp_path / f"pred{world}"
+        for method in ("thermal_only", "early_fusion"):
+            _cli("save_predictions", ["--dataset_path", str(root), "--fusion_method", method, "--prediction_path", str(pdir), "--batch", "4",
+                                      "--world-size", str(world)], env)
+        pred[world] = {m: json.load(open(pdir / f"val_{m}_predictions.json")) for m in ("thermal_only", "early_fusion")}
+    assert pred[1] == pred[2]
+    fused = {}
+    for world in (1, 2):
+        out = tmp_path / f"fuse{world}"
+        _cli("demo_probEn", ["--dataset_path", str(root), "--prediction_path", str(tmp_path / "pred1"), "--detectors", "thermal_only,early_fusion",
+                             "--outfolder", str(out), "--dataset_name", f"flir_p{world}", "--world-size", str(world)], env)
+        fused[world] = (json.load(open(out / "FLIR_probEn_eval.json")), json.load(open(out / "coco_instances_results.json")))
+    assert fused[1] == fused[2] and len(fused[1][1]) > 10
+
+
+def test_world_size_2_kaist_rows_are_byte_identical(tmp_path):
+    import torch
+    from PIL import Image
+    from proben_amd.synthetic import synthetic_images
+    two = torch.cuda.device_count() >= 2
+    root = tmp_path / "KAIST"
+    th, rgb = synthetic_images(6, 256, 320, seed=61), synthetic_images(6, 256, 320, seed=62)
+    lines = []
+    for i in range(6):
+        d = root / "test" / "set06" / f"V00{i % 2}"
+        (d / "lwir").mkdir(parents=True, exist_ok=True)
+        (d / "visible").mkdir(parents=True, exist_ok=True)
+        Image.fromarray(th[i]).save(d / "lwir" / f"I{i:05d}.jpg", quality=95)
+        Image.fromarray(rgb[i]).save(d / "visible" / f"I{i:05d}.jpg", quality=95)
+        lines.append(f"set06/V00{i % 2}/I{i:05d}")
+    split = tmp_path / "split.txt"
+    split.write_text("\n".join(lines) + "\n")
+    env = _env(two)
+    for method in ("thermal_only", "probEn"):      # single detector; configs[4]'s two-detector binary ProbEn
+        blobs = {}
+        for world in (1, 2):
+            out = tmp_path / f"{method}{world}"
+            _cli("demo_LAMR_KAIST", ["--dataset_path", str(root), "--split_file", str(split), "--fusion_method", method,
+                                     "--out_folder", str(out), "--batch", "2", "--world-size", str(world)], env)
+            blobs[world] = open(out / f"KAIST_{method}_result.txt", "rb").read()
+        assert blobs[1] == blobs[2] and blobs[1].count(b"\n") > 5, method
