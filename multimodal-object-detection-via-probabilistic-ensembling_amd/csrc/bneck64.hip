@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256, 2) void bneck64_kernel(B64Args a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) t2f[i][j][e] = (_Float16)fmaxf(acc2[j >> 1][i][(j & 1) * 8 + e], 0.f);
+            for (int e = 0; e < 8; ++e) t2f[i][j][e] = (_Float16)pe::relu_nan(acc2[j >> 1][i][(j & 1) * 8 + e]);
 
     // ---- phase 2: per 64-channel chunk of the 256 outputs: conv3 (+ shortcut convolution), shortcut, ReLU, store,
     //      and the chunk's contribution to the next block's conv1 ----
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256, 2) void bneck64_kernel(B64Args a) {
                 for (int e = 0; e < 8; ++e) {
                     float v = acc3[q >> 1][i][(q & 1) * 8 + e];
                     if (!SC) v += (float)rv[i][q][e];
-                    of[i][q][e] = (_Float16)fmaxf(v, 0.f);
+                    of[i][q][e] = (_Float16)pe::relu_nan(v);
                 }
         if (!SC && c + 1 < 4) res_load(c + 1);   // next chunk's shortcut rows: in flight across the stores and the MFMAs below
         // Stores: a lane owns 64 bytes of one pixel, so a direct store instruction is 64 scattered 16-byte pieces - partial
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256, 2) void bneck64_kernel(B64Args a) {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) tn[i][q][e] = (_Float16)fmaxf(acc4[q >> 1][i][(q & 1) * 8 + e], 0.f);
+                for (int e = 0; e < 8; ++e) tn[i][q][e] = (_Float16)pe::relu_nan(acc4[q >> 1][i][(q & 1) * 8 + e]);
         stage_rows(tn);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {

@@ -47,6 +47,11 @@ __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ unsigned long long lanemask_lt() {
     return (1ull << (threadIdx.x & 63)) - 1ull;
 }
+// ReLU / max-pool maxima propagate NaN like torch's relu_ and max_pool2d (fmaxf / v_max_f32 return the OTHER operand for a
+// NaN and would turn a poisoned activation into a clean 0: the reference's robustness contract - NaN / inf features give no
+// proposals and no detections, tests/test_model_e2e.py:91-120 - depends on NaN surviving).  gfx950: one v_maximum3_f32.
+__device__ __forceinline__ float relu_nan(float x) { return __builtin_elementwise_maximum(x, 0.f); }
+
 static inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 }  // namespace pe

@@ -117,7 +117,7 @@ __device__ __forceinline__ void epilogue(const Conv2Args& a, float16v (&acc)[2][
             }
             if (a.relu) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) x[e] = fmaxf(x[e], 0.f);
+                for (int e = 0; e < 8; ++e) x[e] = pe::relu_nan(x[e]);
             }
             if (a.out_f32) {
                 float* o = reinterpret_cast<float*>(a.out) + (size_t)m * a.out_stride + c;
@@ -203,7 +203,7 @@ __device__ __forceinline__ void epilogue256(const Conv2Args& a, float16v (&acc)[
             }
             if (a.relu) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) x[e] = fmaxf(x[e], 0.f);
+                for (int e = 0; e < 8; ++e) x[e] = pe::relu_nan(x[e]);
             }
             half8 h;
 #pragma unroll

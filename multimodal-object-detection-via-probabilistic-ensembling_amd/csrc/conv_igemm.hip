@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         }
         if (a.relu) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) x[e] = fmaxf(x[e], 0.f);
+            for (int e = 0; e < 8; ++e) x[e] = pe::relu_nan(x[e]);
         }
         if (a.out_f32) {
             float* o = reinterpret_cast<float*>(a.out) + (size_t)m * a.out_stride + c;

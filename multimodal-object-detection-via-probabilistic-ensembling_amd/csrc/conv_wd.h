@@ -270,7 +270,7 @@ __global__ __launch_bounds__(64 * WM * WN, (TPX <= 4 ? 2 : 1)) void conv3x3_wd_k
 #pragma unroll
             for (int i = 0; i < TPX; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[blk][i][r] = fmaxf(acc[blk][i][r], 0.f);
+                for (int r = 0; r < 16; ++r) acc[blk][i][r] = pe::relu_nan(acc[blk][i][r]);
     }
     if constexpr (HEAD == 1) {
         static_assert(WM == 1 && WN == 4 && TPX == 4, "fused head: one 128-pixel x 256-channel tile per workgroup");
@@ -435,7 +435,7 @@ __global__ __launch_bounds__(64 * WM * WN, (TPX <= 4 ? 2 : 1)) void conv3x3_wd_k
                     for (int hh = 0; hh < 2; ++hh) {
                         half8 v;
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = (_Float16)fmaxf(acc[blk][i][hh * 8 + e], 0.f);
+                        for (int e = 0; e < 8; ++e) v[e] = (_Float16)pe::relu_nan(acc[blk][i][hh * 8 + e]);
                         *reinterpret_cast<half8*>(o + blk * 16 + hh * 8) = v;
                     }
             }

@@ -146,7 +146,7 @@ __global__ void maxpool3x3s2_kernel(const _Float16* in, _Float16* out, int N, in
                 if ((unsigned)iw >= (unsigned)W) continue;
                 const half8 v = *reinterpret_cast<const half8*>(in + (((size_t)n * H + ih) * W + iw) * C + c8 * 8);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], (float)v[e]);
+                for (int e = 0; e < 8; ++e) m[e] = __builtin_elementwise_maximum(m[e], (float)v[e]);
             }
         }
         half8 o;

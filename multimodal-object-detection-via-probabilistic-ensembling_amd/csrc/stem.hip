@@ -136,8 +136,8 @@ __global__ __launch_bounds__(THREADS, 2) void stem7x7_pool_kernel(StemArgs a) {
                     half4 o0, o1;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        o0[i] = (_Float16)(valid ? fmaxf(acc0[j * 4 + i] + bv[0][j][i], 0.f) : 0.f);
-                        o1[i] = (_Float16)(valid ? fmaxf(acc1[j * 4 + i] + bv[1][j][i], 0.f) : 0.f);
+                        o0[i] = (_Float16)(valid ? pe::relu_nan(acc0[j * 4 + i] + bv[0][j][i]) : 0.f);
+                        o1[i] = (_Float16)(valid ? pe::relu_nan(acc1[j * 4 + i] + bv[1][j][i]) : 0.f);
                     }
                     *reinterpret_cast<half4*>(dst + 8 * j) = o0;
                     *reinterpret_cast<half4*>(dst + 32 + 8 * j) = o1;
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(THREADS, 2) void stem7x7_pool_kernel(StemArgs a) {
 #pragma unroll
                 for (int dx = 0; dx < 3; ++dx) {
                     if (dy == 0 && dx == 0) continue;
-                    m = __builtin_elementwise_max(m, *reinterpret_cast<const half8*>(src + (dy * CC + dx) * OPITCH));
+                    m = __builtin_elementwise_maximum(m, *reinterpret_cast<const half8*>(src + (dy * CC + dx) * OPITCH));
                 }
             const int oy = cur.ph0 + pr, ox = cur.pw0 + pcol;
             if (oy < a.Hp && ox < a.Wp)

@@ -140,3 +140,50 @@ def test_r152_matches_oracle():
     """The reference's build_resnet_backbone also offers depth 152 (backbone/resnet.py:515-519): (3, 8, 36, 3) blocks."""
     want, inter, det, _ = run_pair(152, hw=(256, 320), n_images=2)
     check_pair(want, inter, det)
+
+
+@pytest.mark.parametrize("bad", [float("inf"), float("nan")])
+def test_model_level_inf_nan_contract(bad):
+    """The reference's robustness contract (tests/test_model_e2e.py:91-120): all-inf / all-NaN pyramid features -> the
+    proposal generator returns 0 proposals; one regular proposal + inf / NaN features -> the ROI heads return 0 detections;
+    and, end to end, a NaN / inf input image leaves no detection (and never hangs or writes out of range)."""
+    import proben_amd  # noqa: F401
+    from proben_amd.rcnn import DetectorConfig, GeneralizedRCNN
+    from proben_amd.synthetic import synthetic_state_dict
+    model = GeneralizedRCNN(DetectorConfig(), synthetic_state_dict(50, 3, 3, seed=1))
+    dev = model.device
+    N, H, W = 1, 512, 512
+    feats = [torch.full((N, H // s, W // s, 256), bad, dtype=torch.float16, device=dev) for s in (4, 8, 16, 32, 64)]
+    sizes = model._size_table([(510, 510)])
+    # ---- proposal generator on bad features (the RPN head convolutions run: inf * w and NaN both poison the logits) ----
+    props, plog, pcnt, heads = model._rpn(feats, sizes, N)
+    torch.cuda.synchronize()
+    assert int(pcnt[0]) == 0
+    assert not torch.isfinite(heads[0]).any()
+    # ---- the same through the `heads=` injection point (fp32 head rows that are bad from the start) ----
+    bad_heads = [torch.full((N, H // s, W // s, 16), bad, dtype=torch.float32, device=dev) for s in (4, 8, 16, 32, 64)]
+    _, _, pcnt2, _ = model._rpn(feats, sizes, N, heads=bad_heads)
+    assert int(pcnt2[0]) == 0
+    # ---- ROI heads: one regular proposal, bad features ----
+    P = model.cfg.post_nms_topk
+    one = torch.zeros((N, P, 4), dtype=torch.float32, device=dev)
+    one[0, 0] = torch.tensor([10.0, 10.0, 20.0, 20.0])
+    cnt1 = torch.ones((N,), dtype=torch.int32, device=dev)
+    det = model._roi_heads(feats, one, cnt1, sizes, sizes, N)
+    torch.cuda.synchronize()
+    assert int(det["counts"][0]) == 0
+    # ... and through the `head=` injection point (bad predictor rows)
+    bad_head = torch.full((N * P, model.w.head_stride), bad, dtype=torch.float32, device=dev)
+    det = model._roi_heads(feats, one, cnt1, sizes, sizes, N, head=bad_head)
+    assert int(det["counts"][0]) == 0
+    # ---- end to end: a bad input image ----
+    img = torch.full((3, 256, 320), bad, dtype=torch.float32, device=dev)
+    out = model([{"image": img, "height": 256, "width": 320}])
+    assert len(out[0]["instances"]) == 0
+    # a good image next to a bad one keeps its detections (images do not contaminate each other inside a batch)
+    from proben_amd.synthetic import synthetic_images
+    good = torch.from_numpy(synthetic_images(1, 256, 320, seed=3)[0]).permute(2, 0, 1).float().to(dev)
+    alone = model([{"image": good}])[0]["instances"]
+    both = model([{"image": good}, {"image": img}])
+    assert len(both[1]["instances"]) == 0 and len(both[0]["instances"]) == len(alone)
+    assert torch.equal(both[0]["instances"].pred_boxes.tensor, alone.pred_boxes.tensor)
