@@ -62,7 +62,6 @@ def parse(argv=None):
     ap.add_argument("--no-micro", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=8)
     ap.add_argument("--cpu-threads", type=int, default=16)
-    ap.add_argument("--conv-impl", type=int, default=2, help="1: register-staged conv kernel, 2: LDS-DMA conv kernels")
     ap.add_argument("--no-wd", action="store_true", help="A/B: do not use the weights-direct 3x3 kernel")
     ap.add_argument("--no-tail-fusion", action="store_true", help="A/B: run conv2 and conv3 of the res4 bottlenecks as two launches")
     ap.add_argument("--no-res2-fusion", action="store_true", help="A/B: run res2 as separate conv launches instead of the fused 64-wide chain")
@@ -71,7 +70,6 @@ def parse(argv=None):
                     help="N > 0 (default 3, two-detector configs): throughput mode of the pipeline - detector 2 trails detector 1 by its "
                          "res<N> stage and batches follow each other without a device-wide wait (all K timed steps still complete "
                          "inside the timed region); 0: every step waits for its own fusion before the next one starts")
-    ap.add_argument("--tile256", type=int, default=-1, help="conv tile policy override (pe_set_conv_tile256)")
     ap.add_argument("--layers", type=str, default="", help="write a per-conv-launch table (shape, ms, TFLOP/s) to this file")
     return ap.parse_args(argv)
 
@@ -344,10 +342,6 @@ def main(argv=None):
     depth = args.depth or cfg["depth"]
     B = args.batch or cfg["batch"]
     models, sds = build_models(cfg, depth, dev, use_wd=not args.no_wd, fuse_tails=not args.no_tail_fusion, fuse_res2=not args.no_res2_fusion)
-    from proben_amd import _lib
-    _lib.check(_lib.lib().pe_set_conv_impl(args.conv_impl), "pe_set_conv_impl")
-    if args.tile256 >= 0:
-        _lib.lib().pe_set_conv_tile256(args.tile256)
     feeder = None
     if args.feed == "host":
         from proben_amd.pipeline import HostFeeder

@@ -111,15 +111,7 @@ int pe_conv2d_nhwc_f16(const void* input, const void* weight, const float* bias,
                        int32_t kernel, int32_t stride, int32_t relu, int32_t residual_mode,
                        int32_t res_h, int32_t res_w, int32_t out_f32, int32_t cout_store,
                        int32_t out_stride, void* stream);
-/* Implementation switch for A/B measurements (thread-safe: one relaxed atomic each; a change affects launches issued
- * after it): 1 = register-staged double-buffered kernel, 2 (default) = LDS-DMA (global_load_lds) kernels incl. the
- * kw-reuse 3x3 kernel, 3 = LDS-DMA kernels with the generic (per-tap) 3x3.  The 7x7 stem always uses 1. */
-int pe_set_conv_impl(int32_t impl);
-/* Kernel-selection policy bits of pe_conv2d_nhwc_f16 (A/B measurements; default 9 = 1|8):
- *   1: 256-row block tiles (8 waves) for 3x3 launches with >= 512 such tiles     2: the same for 1x1 launches
- *   4: two-stage pipeline in the generic 1x1 kernel                              8: 256x256 two-stage kernel for long-K GEMMs
- *  16: 256x256 kernel for every eligible launch */
-int pe_set_conv_tile256(int32_t mode);
+/* (kernel-selection knobs for A/B measurements are not part of this ABI: csrc/test_hooks.h) */
 
 /* ---------------------------------------------------------------------------------------------
  * "Weights-direct" 3x3 convolution (csrc/conv_wd.h): same reference rows as pe_conv2d_nhwc_f16 with kernel 3

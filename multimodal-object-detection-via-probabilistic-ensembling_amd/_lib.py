@@ -17,8 +17,6 @@ SIGNATURES = {
     "pe_proben_pack_detections": [c_void_p] * 6 + [c_int] * 6 + [c_void_p] * 9,
     "pe_proben_fuse_batch": [c_void_p] * 8 + [c_int] * 5 + [c_double] * 3 + [c_void_p] * 5 + [c_void_p],
     "pe_conv2d_nhwc_f16": [c_void_p] * 5 + [c_int] * 14 + [c_void_p],
-    "pe_set_conv_impl": [c_int],
-    "pe_set_conv_tile256": [c_int],
     "pe_conv_wd_supported": [c_int] * 6,
     "pe_conv_wd_pack_weights": [c_void_p] * 2 + [c_int] * 3 + [c_void_p],
     "pe_conv3x3_wd_f16": [c_void_p] * 4 + [c_int] * 7 + [c_void_p],
@@ -53,6 +51,10 @@ _RESTYPE = {"pe_last_error": ctypes.c_char_p, "pe_nms_scratch_bytes": ctypes.c_s
              "pe_bneck64_packed_bytes": ctypes.c_size_t}
 
 
+# exported for tests/ and scripts/ only (csrc/test_hooks.h) - not in include/proben_hip.h
+TEST_HOOKS = {"pe_test_set_conv_policy": [c_int, c_int]}
+
+
 class HipLibraryError(RuntimeError):
     pass
 
@@ -74,6 +76,15 @@ def lib():
             fn.restype = _RESTYPE.get(name, ctypes.c_int)
         _lib = L
     return _lib
+
+
+def test_hooks():
+    """The library with the measurement hooks of csrc/test_hooks.h typed (tests/ and scripts/ only)."""
+    L = lib()
+    for name, args in TEST_HOOKS.items():
+        fn = getattr(L, name)
+        fn.argtypes, fn.restype = args, ctypes.c_int
+    return L
 
 
 def check(status, what):

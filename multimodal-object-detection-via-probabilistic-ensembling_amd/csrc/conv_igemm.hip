@@ -18,8 +18,6 @@
 //   m-tiles (3x3 halo) sit on one XCD's L2.
 #include <hip/hip_fp16.h>
 
-#include <atomic>
-
 #include "common.h"
 
 namespace {
@@ -283,25 +281,7 @@ namespace pe {
 int conv2_dispatch(const void* in, const void* wgt, const float* bias, const void* res, void* out, int N, int H, int W,
                    int Cin, int Cout, int Ho, int Wo, int K, int M, int mode3x3, int stride, int relu, int res_mode,
                    int resH, int resW, int out_f32, int cout_store, int out_stride, hipStream_t st);
-extern std::atomic<int> g_conv3x3_reuse;
-extern std::atomic<int> g_conv_tile256;
-static std::atomic<int> g_conv_impl{2};  // 1: register-staged double-buffer kernel (this file); 2: LDS-DMA kernel (conv_igemm2.hip)
 }  // namespace pe
-
-extern "C" int pe_set_conv_impl(int impl) {
-    if (impl < 1 || impl > 3) {
-        pe::set_error("pe_set_conv_impl: impl %d not in {1,2,3}", impl);
-        return PE_ERR_INVALID_ARG;
-    }
-    pe::g_conv_impl = impl == 1 ? 1 : 2;
-    pe::g_conv3x3_reuse = impl == 2 ? 1 : 0;
-    return PE_OK;
-}
-
-extern "C" int pe_set_conv_tile256(int mode) {
-    pe::g_conv_tile256 = mode;
-    return PE_OK;
-}
 
 extern "C" int pe_conv2d_nhwc_f16(const void* input, const void* weight, const float* bias, const void* residual,
                                   void* output, int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
@@ -337,12 +317,11 @@ extern "C" int pe_conv2d_nhwc_f16(const void* input, const void* weight, const f
     PE_CHECK_ARG(M < (1ll << 31), "pe_conv2d_nhwc_f16: M too large");
     a.M = (int)M;
     hipStream_t st = (hipStream_t)stream;
-    if (pe::g_conv_impl == 2 && mode != MODE_STEM)
+    if (mode != MODE_STEM)
         return pe::conv2_dispatch(input, weight, bias, residual, output, N, H, W, Cin, Cout, a.Ho, a.Wo, a.K, a.M,
                                   mode == MODE_3X3, stride, relu, residual_mode, res_h, res_w, out_f32, a.cout_store,
                                   a.out_stride, st);
-    const bool narrow = Cout <= 64;
-    if (mode == MODE_1X1) return narrow ? launch<128, 64, MODE_1X1>(a, st) : launch<128, 128, MODE_1X1>(a, st);
-    if (mode == MODE_3X3) return narrow ? launch<128, 64, MODE_3X3>(a, st) : launch<128, 128, MODE_3X3>(a, st);
+    // the unfused 7x7 stem (inputs whose H or W is not a multiple of 4; otherwise stem.hip's one-pass kernel runs): the only
+    // launch left on this file's register-staged kernel
     return launch<128, 64, MODE_STEM>(a, st);
 }

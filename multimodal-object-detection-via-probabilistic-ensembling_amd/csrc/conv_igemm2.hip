@@ -462,7 +462,7 @@ int launch2(const Conv2Args& a0, hipStream_t st) {
 namespace pe {
 std::atomic<int> g_conv_tile256{9};   // bit 0: 256-row tiles for big 3x3 launches, bit 1: for big 1x1 launches, bit 2: two-stage 1x1 pipeline,
                                       // bit 3: 256x256 two-stage kernel for long-K GEMMs, bit 4: ... for every eligible launch
-std::atomic<int> g_conv3x3_reuse{1};  // pe_set_conv_impl(3) turns the kw-reuse 3x3 kernel off (A/B measurements)
+std::atomic<int> g_conv3x3_reuse{1};  // 0: the generic per-tap 3x3 kernel instead of the kw-reuse one (A/B measurements)
 // called from pe_conv2d_nhwc_f16 (conv_igemm.hip) for the 1x1 / 3x3 cases
 int conv2_dispatch(const void* in, const void* wgt, const float* bias, const void* res, void* out, int N, int H, int W,
                    int Cin, int Cout, int Ho, int Wo, int K, int M, int mode3x3, int stride, int relu, int res_mode,
@@ -493,3 +493,12 @@ int conv2_dispatch(const void* in, const void* wgt, const float* bias, const voi
     return big1 ? launch2<256, 128, MODE_1X1>(a, st) : launch2<128, 128, MODE_1X1>(a, st);
 }
 }  // namespace pe
+
+// Measurement / test hook - deliberately NOT part of include/proben_hip.h (csrc/test_hooks.h): selects among kernels that all
+// compute the same convolution, so that tests can cover every variant and scripts/ablate_conv.py can A/B them.
+extern "C" int pe_test_set_conv_policy(int tile_bits, int reuse3x3) {
+    pe::g_conv_tile256 = tile_bits;
+    pe::g_conv3x3_reuse = reuse3x3 ? 1 : 0;
+    return PE_OK;
+}
+

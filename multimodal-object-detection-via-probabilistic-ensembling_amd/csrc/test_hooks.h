@@ -1,0 +1,15 @@
+// Exported by libproben_hip.so for tests/ and scripts/ ONLY - not part of the drop-in C-ABI (include/proben_hip.h), not bound by the
+// product's Python surface except through proben_amd._lib.test_hooks().
+#pragma once
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* Kernel-selection policy of pe_conv2d_nhwc_f16 (process-global, relaxed atomics; affects launches issued afterwards).
+ *   tile_bits (default 9 = 1|8):  1: 256-row block tiles (8 waves) for 3x3 launches with >= 512 such tiles   2: the same for 1x1
+ *                                 4: two-stage pipeline in the generic 1x1 kernel   8: 256x256 two-stage kernel for long-K GEMMs
+ *                                16: 256x256 kernel for every eligible launch
+ *   reuse3x3 (default 1): 1 = kw-reuse 3x3 kernel, 0 = generic per-tap 3x3 kernel */
+int pe_test_set_conv_policy(int tile_bits, int reuse3x3);
+#ifdef __cplusplus
+}
+#endif

@@ -139,3 +139,39 @@ def synthetic_images(n, height=512, width=640, channels=3, seed=0, structured=Tr
                 w, h = int(rng.integers(30, 200)), int(rng.integers(30, 200))
                 imgs[i, y0:y0 + h, x0:x0 + w] = (imgs[i, y0:y0 + h, x0:x0 + w] // 4 + int(rng.integers(0, 192))).astype(np.uint8)
     return imgs
+
+
+def labelled_frames(n, height=512, width=640, seed=0, max_objects=6):
+    """uint8 BGR-order frames with KNOWN objects (for the pseudo-trained-head parity harness, tests/golden/gen_pseudo_heads.py):
+    mid-grey noise background and up to `max_objects` non-overlapping rectangles whose appearance encodes their class -
+    0 'person': bright and smooth, 1 'bicycle': dark and smooth, 2 'car': 8-pixel checkerboard of both - so that even a
+    random-feature box head can be fitted to tell them apart.  Returns (frames [n,H,W,3], list of (boxes [m,4] xyxy float32,
+    classes [m] int64))."""
+    rng = np.random.default_rng(seed)
+    frames = rng.normal(128.0, 30.0, size=(n, height, width, 3)).clip(0, 255).astype(np.uint8)
+    yy, xx = np.mgrid[0:height, 0:width]
+    checker = (((yy // 8) + (xx // 8)) % 2).astype(bool)
+    gts = []
+    for i in range(n):
+        boxes, classes = [], []
+        for _ in range(40):
+            if len(boxes) >= max_objects:
+                break
+            w, h = int(rng.integers(48, 220)), int(rng.integers(48, 200))
+            x0, y0 = int(rng.integers(4, width - w - 4)), int(rng.integers(4, height - h - 4))
+            if any(x0 < b[2] + 12 and b[0] < x0 + w + 12 and y0 < b[3] + 12 and b[1] < y0 + h + 12 for b in boxes):
+                continue
+            c = int(rng.integers(0, 3))
+            patch = frames[i, y0:y0 + h, x0:x0 + w]
+            noise = rng.normal(0.0, 6.0, size=patch.shape)
+            if c == 0:
+                val = 225.0 + noise
+            elif c == 1:
+                val = 25.0 + noise
+            else:
+                val = np.where(checker[y0:y0 + h, x0:x0 + w, None], 235.0, 15.0) + noise
+            frames[i, y0:y0 + h, x0:x0 + w] = val.clip(0, 255).astype(np.uint8)
+            boxes.append([x0, y0, x0 + w, y0 + h])
+            classes.append(c)
+        gts.append((np.asarray(boxes, dtype=np.float32).reshape(-1, 4), np.asarray(classes, dtype=np.int64)))
+    return frames, gts

@@ -22,7 +22,7 @@ def timeit(fn, reps=20):
 
 
 def main():
-    lib = _lib.lib()
+    hooks = _lib.test_hooks()   # csrc/test_hooks.h: kernel-selection policy (not part of the product ABI)
     shapes = [(32, 200, 256, 256, 256, 3), (32, 50, 64, 256, 256, 3), (32, 100, 128, 256, 256, 3), (32, 50, 64, 1024, 256, 1),
               (32, 50, 64, 256, 1024, 1), (32000, 1, 1, 12544, 1024, 1)]
     for (N, H, W, Cin, Cout, k) in shapes:
@@ -32,13 +32,12 @@ def main():
         out = torch.empty(N, H, W, Cout, device="cuda", dtype=torch.float16)
         fl = 2.0 * N * H * W * Cout * k * k * Cin
         row = []
-        for impl, tile in [(1, 1), (3, 1), (2, 0), (2, 1), (2, 3), (2, 9), (2, 25)]:
-            lib.pe_set_conv_impl(impl)
-            lib.pe_set_conv_tile256(tile)
+        # (reuse3x3, tile bits); the register-staged first-generation kernel ("i1" in the r01 / r02 tables) left the library in r03
+        for reuse, tile in [(0, 1), (1, 0), (1, 1), (1, 3), (1, 9), (1, 25)]:
+            hooks.pe_test_set_conv_policy(tile, reuse)
             ms = timeit(lambda: L.conv2d_nhwc(x, w, b, kernel=k, relu=True, out=out))
-            row.append(f"i{impl}t{tile}: {ms:.4f}ms {fl / ms / 1e9:6.0f}TF")
-        lib.pe_set_conv_impl(2)
-        lib.pe_set_conv_tile256(9)
+            row.append(f"{'kw-reuse' if reuse else 'per-tap'} t{tile}: {ms:.4f}ms {fl / ms / 1e9:6.0f}TF")
+        hooks.pe_test_set_conv_policy(9, 1)
         if k == 3 and L.conv_wd_supported(3, 1, H, W, Cin, Cout):
             pk = L.conv_wd_pack(w)
             ms = timeit(lambda: L.conv3x3_wd(x, pk, b, Cout, relu=True, out=out))

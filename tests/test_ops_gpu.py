@@ -77,7 +77,7 @@ def test_conv_big_tile_kernel(L, case, policy):
     """The 256x256 two-stage kernel (tile policy bit 3) against torch, incl. ragged M, residual modes, stride 2."""
     import proben_amd
     N, H, W, Cin, Cout, k, s, relu, res_mode = case
-    lib = proben_amd._lib.lib()
+    hooks = proben_amd._lib.test_hooks()
     g = torch.Generator(device="cpu").manual_seed(11)
     x = torch.randn(N, Cin, H, W, generator=g).cuda().half()
     w = (torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).cuda().half()
@@ -95,12 +95,12 @@ def test_conv_big_tile_kernel(L, case, policy):
     if relu:
         ref = ref.relu()
     # 25: 256x256 two-stage kernel everywhere it applies
-    lib.pe_set_conv_tile256(policy)
+    hooks.pe_test_set_conv_policy(policy, 1)
     try:
         out = L.conv2d_nhwc(nhwc(x), w.permute(0, 2, 3, 1).contiguous(), b, kernel=k, stride=s, relu=relu, residual=res, residual_mode=res_mode)
         torch.cuda.synchronize()
     finally:
-        lib.pe_set_conv_tile256(9)
+        hooks.pe_test_set_conv_policy(9, 1)
     torch.testing.assert_close(out.permute(0, 3, 1, 2).float(), ref, rtol=4e-3, atol=4e-3)
 
 
@@ -110,7 +110,7 @@ def test_conv3x3_weight_double_buffered_kernel(L, case):
     """The kw-reuse 3x3 kernel with the double-buffered weight tile, 128- and 256-row tiles."""
     import proben_amd
     N, H, W, Cin, Cout, k, s, relu, rows = case
-    lib = proben_amd._lib.lib()
+    hooks = proben_amd._lib.test_hooks()
     g = torch.Generator(device="cpu").manual_seed(13)
     x = torch.randn(N, Cin, H, W, generator=g).cuda().half()
     w = (torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).cuda().half()
@@ -118,12 +118,12 @@ def test_conv3x3_weight_double_buffered_kernel(L, case):
     ref = torch.nn.functional.conv2d(x.float(), w.float(), b, stride=s, padding=1)
     if relu:
         ref = ref.relu()
-    lib.pe_set_conv_tile256(9)
+    hooks.pe_test_set_conv_policy(9, 1)
     try:
         out = L.conv2d_nhwc(nhwc(x), w.permute(0, 2, 3, 1).contiguous(), b, kernel=k, stride=s, relu=relu)
         torch.cuda.synchronize()
     finally:
-        lib.pe_set_conv_tile256(9)
+        hooks.pe_test_set_conv_policy(9, 1)
     torch.testing.assert_close(out.permute(0, 3, 1, 2).float(), ref, rtol=4e-3, atol=4e-3)
 
 

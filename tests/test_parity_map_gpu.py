@@ -1,0 +1,99 @@
+"""north_star: "demo_mAP_FLIR reproduces the reference mAP within 1e-3".  Neither FLIR nor its checkpoints exist offline, so the
+contract is measured on the closest thing that can be built here: R101-FPN with seeded random backbone and
+box-head FCs whose RPN and box-predictor layers were FITTED on frames with known objects (tests/golden/gen_pseudo_heads.py), so
+that scores separate like a trained model's.  The oracle (= restatement of the reference's CPU path; its detections with these
+weights are the committed fixture) and the HIP detector are scored against the SAME ground truth with the same COCO evaluator
+(evaluation/FLIR_evaluation.py:249-310's protocol, csrc/cocoeval.cpp) and the two AP tables are compared.
+The measured deltas are written to gpurun_out/r03/map_parity.json (copied to profiles/ by hand)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def coco_stats(gts, rows, hw=(512, 640)):
+    from proben_amd import evaluation
+    images = [{"id": i, "height": hw[0], "width": hw[1], "file_name": f"{i}.jpeg"} for i in range(len(gts))]
+    cats = [{"id": 1, "name": "person"}, {"id": 2, "name": "bicycle"}, {"id": 3, "name": "car"}]
+    anns, aid = [], 1
+    for i, (b, c) in enumerate(gts):
+        for bb, cc in zip(b, c):
+            w, h = float(bb[2] - bb[0]), float(bb[3] - bb[1])
+            anns.append({"id": aid, "image_id": i, "category_id": int(cc) + 1, "bbox": [float(bb[0]), float(bb[1]), w, h], "area": w * h, "iscrowd": 0})
+            aid += 1
+    dets = [{"image_id": int(r[0]), "category_id": int(r[6]) + 1, "bbox": [float(r[1]), float(r[2]), float(r[3] - r[1]), float(r[4] - r[2])],
+             "score": float(r[5])} for r in rows]
+    ev = evaluation.COCOevalBBox({"images": images, "annotations": anns, "categories": cats}, dets, impl="native")
+    ev.evaluate()
+    ev.accumulate()
+    return np.asarray(ev.summarize(printer=None), dtype=np.float64)
+
+
+def load_fixture(golden_dir):
+    import proben_amd  # noqa: F401
+    from proben_amd.synthetic import labelled_frames, synthetic_state_dict
+    z = np.load(os.path.join(golden_dir, "pseudo_heads_r101.npz"))
+    sd = synthetic_state_dict(int(z["depth"]), 3, 3, seed=int(z["seed"]))
+    for k in z.files:
+        if "/" in k:
+            sd[k.replace("/", ".")] = torch.from_numpy(z[k])
+    frames, gts = labelled_frames(int(z["n_eval"]), seed=int(z["eval_seed"]))
+    return z, sd, frames, gts
+
+
+def test_map_of_hip_and_oracle_against_the_same_ground_truth(golden_dir):
+    from proben_amd.data import resize_shortest_edge_shape
+    from proben_amd.rcnn import DetectorConfig, GeneralizedRCNN
+    z, sd, frames, gts = load_fixture(golden_dir)
+    ora_rows = z["oracle_rows"]
+    ora = coco_stats(gts, ora_rows)
+    np.testing.assert_allclose(ora, z["oracle_stats"], rtol=0, atol=1e-12)      # the fixture's own table re-derives
+    model = GeneralizedRCNN(DetectorConfig(), sd)
+    new_hw = resize_shortest_edge_shape(512, 640, 800, 1333)
+    rows = []
+    for b0 in range(0, len(frames), 16):
+        fr = torch.from_numpy(frames[b0:b0 + 16]).cuda()
+        det = model.forward_batch(fr, out_sizes=[(512, 640)] * len(fr), resize_to=new_hw)
+        cnt = det["counts"].cpu().tolist()
+        for i, c in enumerate(cnt):
+            bx, sc, cl = det["boxes"][i, :c].cpu().numpy(), det["scores"][i, :c].cpu().numpy(), det["classes"][i, :c].cpu().numpy()
+            rows += [[b0 + i, *bx[j], sc[j], cl[j]] for j in range(c)]
+    rows = np.asarray(rows, dtype=np.float32).reshape(-1, 7)
+    hip = coco_stats(gts, rows)
+    names = ["AP", "AP50", "AP75", "APs", "APm", "APl"]
+    rec = {"model": "R101-FPN, seeded random backbone / FCs, fitted RPN + box predictor (tests/golden/gen_pseudo_heads.py)",
+           "frames": int(len(frames)), "ground_truth_objects": int(sum(len(g[0]) for g in gts)),
+           "oracle_detections": int(len(ora_rows)), "hip_detections": int(len(rows)),
+           "oracle": {n: float(ora[i] * 100) for i, n in enumerate(names)}, "hip": {n: float(hip[i] * 100) for i, n in enumerate(names)},
+           "delta": {n: float((hip[i] - ora[i]) * 100) for i, n in enumerate(names)},
+           "north_star_tolerance_points": 0.1}
+    out = os.path.join(ROOT, "gpurun_out", "r03")
+    os.makedirs(out, exist_ok=True)
+    json.dump(rec, open(os.path.join(out, "map_parity.json"), "w"), indent=1)
+    print(json.dumps(rec, indent=1))
+    assert ora[1] > 0.5, "the fitted heads must give a meaningful detector (AP50 of the oracle > 50)"
+    # "mAP within 1e-3" = 0.1 AP point on the evaluator's 0-100 scale
+    assert abs(hip[1] - ora[1]) * 100 <= 0.1, rec["delta"]
+    assert abs(hip[0] - ora[0]) * 100 <= 0.1, rec["delta"]
+
+
+def test_committed_oracle_rows_are_what_the_oracle_computes_here(golden_dir):
+    """The fixture was produced in the build container; the same oracle on this box's host cores must reproduce it (first frame)."""
+    from PIL import Image
+    from oracle import detector as D
+    from proben_amd.data import resize_shortest_edge_shape
+    z, sd, frames, _ = load_fixture(golden_dir)
+    new_hw = resize_shortest_edge_shape(512, 640, 800, 1333)
+    r = np.array(Image.fromarray(frames[0]).resize((new_hw[1], new_hw[0]), Image.BILINEAR))
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    o = D.forward([torch.from_numpy(r).permute(2, 0, 1).float().contiguous()], sd, D.DetectorSpec(depth=int(z["depth"])), out_sizes=[(512, 640)])[0]
+    want = z["oracle_rows"][z["oracle_rows"][:, 0] == 0]
+    assert len(o["scores"]) == len(want)
+    np.testing.assert_allclose(o["boxes"].numpy(), want[:, 1:5], rtol=0, atol=2e-2)
+    np.testing.assert_allclose(o["scores"].numpy(), want[:, 5], rtol=0, atol=2e-4)
+    np.testing.assert_array_equal(o["classes"].numpy(), want[:, 6].astype(np.int64))
