@@ -37,14 +37,18 @@ def run_pair(depth=50, hw=(480, 608), n_images=2, seed=1, in_channels=3):
     return want, inter, det, model
 
 
-def check_pair(want, inter, det, min_match=0.85):
+FEATURE_REL = []   # (level, mean relative error) of every check_pair call in this process: printed by the last test
+
+
+def check_pair(want, inter, det, min_match=0.85, feat_rel=2.5e-3):   # measured r03: 0.8e-3 .. 1.2e-3 on every level, R50 / R101 / R152, 3 / 4 / 6 channels
     # ---- features (fp16 vs fp32) ----
     for i, k in enumerate(["p2", "p3", "p4", "p5", "p6"]):
         ref = inter["feats"][k].permute(0, 2, 3, 1).numpy()
         got = det["_feats"][i].float().cpu().numpy()
         assert got.shape == ref.shape
         rel = np.abs(got - ref).mean() / np.abs(ref).mean()
-        assert rel < 2e-2, (k, rel)
+        FEATURE_REL.append((k, float(rel)))
+        assert rel < feat_rel, (k, rel)
     # ---- RPN head logits ----
     ref = inter["rpn_logits"][0].permute(0, 2, 3, 1).numpy()
     got = det["_rpn_heads"][0][..., :3].cpu().numpy()
@@ -187,3 +191,10 @@ def test_model_level_inf_nan_contract(bad):
     both = model([{"image": good}, {"image": img}])
     assert len(both[1]["instances"]) == 0 and len(both[0]["instances"]) == len(alone)
     assert torch.equal(both[0]["instances"].pred_boxes.tensor, alone.pred_boxes.tensor)
+
+
+def test_report_measured_feature_errors():
+    """Not a check of its own: prints what check_pair measured (fp16 pyramid features against the fp32 oracle, mean |diff| /
+    mean |ref| per level) so the bound in check_pair can be compared with the measurement in the log."""
+    for k, rel in FEATURE_REL:
+        print(f"feature error {k}: {rel:.2e}")
