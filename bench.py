@@ -287,6 +287,7 @@ def cpu_baseline(sds, cfg, depth, pairs, threads):
     """The oracle = this repo's restatement of the reference's CPU path (torch fp32 NCHW unfused conv/BN/ReLU,
     all-anchor decode, per-level sort, per-level ROIAlign, NumPy-f64 ProbEn), timed on the host cores: all `threads`
     on `pairs` units, then ONE thread on one unit (SURVEY 8d asks for both)."""
+    import numpy as np
     import torch
     from oracle import detector as D
     from oracle import proben as O
@@ -301,8 +302,12 @@ def cpu_baseline(sds, cfg, depth, pairs, threads):
         for u in range(n_units):
             dets = []
             for sd, spec, im in zip(sds, specs, imgs):
-                x = torch.from_numpy(im[u]).permute(2, 0, 1).float()[None]
-                x = torch.nn.functional.interpolate(x, size=(800, 1000), mode="bilinear", align_corners=False)[0]
+                if im[u].shape[2] == 3:      # 3-channel frames: the reference resizes through Pillow (transform.py:92-97), like the GPU path
+                    from PIL import Image
+                    x = torch.from_numpy(np.array(Image.fromarray(im[u]).resize((1000, 800), Image.BILINEAR))).permute(2, 0, 1).float().contiguous()
+                else:                        # 4- / 6-channel fusion inputs: OpenCV's float bilinear rule (transform.py:82-91)
+                    from oracle.resize import cv2_linear_resize_f64
+                    x = torch.from_numpy(np.ascontiguousarray(cv2_linear_resize_f64(im[u].astype(np.float64), 800, 1000))).permute(2, 0, 1).float().contiguous()
                 o = D.forward([x], sd, spec, out_sizes=[(512, 640)])[0]
                 keep = o["classes"] <= 2
                 dets.append({"bbox": o["boxes"][keep].double().numpy(), "score": o["scores"][keep].double().numpy(),
