@@ -207,7 +207,7 @@ __global__ __launch_bounds__(64 * WM * WN, (TPX <= 4 ? 2 : 1)) void conv3x3_wd_k
 #pragma unroll
     for (int i = 0; i < TPX; ++i) pf[0][i] = *reinterpret_cast<const half8*>(smem + fb[i]);
 
-    static_assert(NP <= 6, "slab pieces are spread over the 12 K-steps of a group");
+    static_assert(NP <= 12, "slab pieces are spread over the 12 K-steps of a group: piece n is loaded in step n and stored in step 12 - NP + n");
     for (int g = 0; g < G; ++g) {
         const int nxt = cur == 2 ? 0 : cur + 1;
         const int nn = nxt == 2 ? 0 : nxt + 1;
