@@ -134,6 +134,11 @@ def make_frames(cfg, B, rank, device=None, pinned=False):
     return out
 
 
+def comm_active():
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized()
+
+
 def make_step(models, frames, cfg, world, with_comm=True, concurrent=True, stagger=0, feeder=None):
     import torch
     from proben_amd.pipeline import FramePairPipeline
@@ -148,7 +153,7 @@ def make_step(models, frames, cfg, world, with_comm=True, concurrent=True, stagg
         dets, fused = pipe(batch, out_sizes, (800, 1000))
         if feeder is not None:
             feeder.mark_consumed(*(pipe.streams or []))
-        if world > 1 and with_comm:
+        if (world > 1 or comm_active()) and with_comm:
             from proben_amd import comm
             payload = fused if fused is not None else {k: dets[0][k] for k in ("boxes", "scores", "classes", "counts")}
             if pipe.staggered:   # the fused rows live on the second detector's stream
@@ -338,7 +343,8 @@ def main(argv=None):
         sys.exit(f"bench.py: WORLD_SIZE {world} != --gpus {args.gpus}")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    force_dist = os.environ.get("PROBEN_FORCE_DIST") == "1" and "RANK" in os.environ   # one-rank RCCL group (exercises the nccl path on a one-GPU box)
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -359,7 +365,7 @@ def main(argv=None):
     step = make_step(models, frames_dev, cfg, world, concurrent=not args.serial_detectors, stagger=stagger, feeder=feeder)
 
     def fence():
-        if world > 1:
+        if world > 1 or comm_active():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -401,8 +407,9 @@ def main(argv=None):
                                            "frames in pinned host memory; double-buffered H2D upload of every batch INSIDE the timed region"),
                        "timed_seconds": round(dt, 2), "schedule": sched},
         }
-        if world > 1:
-            line["config"]["collective"] = "one all_gather_into_tensor of the fused rows per step (RCCL)"
+        if world > 1 or comm_active():
+            line["config"]["collective"] = "one all_gather_into_tensor of the fused rows per step (RCCL)" + ("" if world > 1 else
+                                           "; PROBEN_FORCE_DIST: a ONE-rank RCCL group, the collective runs but moves nothing between devices")
         if not args.no_roofline:
             # rank-local leg: no collective inside (the other ranks are already waiting at the final barrier)
             line["roofline"] = roofline_leg(make_step(models, frames_dev, cfg, world, with_comm=False, concurrent=False), args.layers)
@@ -411,7 +418,7 @@ def main(argv=None):
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(sds, cfg, depth, args.cpu_pairs, args.cpu_threads)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if world > 1 or comm_active():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

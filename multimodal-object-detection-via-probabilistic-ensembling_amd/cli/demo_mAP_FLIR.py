@@ -43,7 +43,7 @@ def main(cmd=None):
 
     def model(inputs):
         return predictor.predict_batch([x["image_np"] for x in inputs])
-    ev = FLIREvaluator(args.dataset_name, cfg, world > 1, output_dir=args.outfolder if comm.is_main_process() else None)
+    ev = FLIREvaluator(args.dataset_name, cfg, world > 1 or comm.is_distributed(), output_dir=args.outfolder if comm.is_main_process() else None)
     res = inference_on_dataset(model, build_detection_test_loader(dicts, mapper), ev)
     if comm.is_main_process():
         print(json.dumps(res, indent=1))
@@ -51,7 +51,7 @@ def main(cmd=None):
             os.makedirs(args.outfolder, exist_ok=True)
             with open(os.path.join(args.outfolder, "FLIR_mAP_results.json"), "w") as f:
                 json.dump({"world_size": world, "results": res}, f)
-    if world > 1:
+    if comm.is_distributed():
         launch.shutdown()
     return res
 

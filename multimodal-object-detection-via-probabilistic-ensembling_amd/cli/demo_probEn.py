@@ -43,13 +43,13 @@ def main(cmd=None):
     with open(val_json) as f:
         hw = {im["id"]: (im["height"], im["width"]) for im in json.load(f)["images"]}
     main_rank = comm.is_main_process()
-    ev = FLIREvaluator(args.dataset_name, cfg, world > 1, output_dir=args.outfolder if main_rank else None, save_eval=main_rank,
+    ev = FLIREvaluator(args.dataset_name, cfg, world > 1 or comm.is_distributed(), output_dir=args.outfolder if main_rank else None, save_eval=main_rank,
                        out_eval_path=os.path.join(args.outfolder, "FLIR_probEn_eval.json"))
     res = apply_late_fusion_and_evaluate(cfg, ev, dets[0], dets[1], [args.score_fusion, args.box_fusion],
                                          det_3=dets[2] if len(dets) > 2 else "", image_hw=hw, device=str(dev))
     if main_rank:
         print(json.dumps(res, indent=1))
-    if world > 1:
+    if comm.is_distributed():
         launch.shutdown()
     return res
 

@@ -91,7 +91,7 @@ def main(cmd=None):
         merged = {k: sum((g[k] for g in gathered), []) for k in pred}      # rank order == dataset order
         write_j1(out, merged)
         print("out file:", out)
-    if world > 1:
+    if comm.is_distributed():
         launch.shutdown()
     return out
 

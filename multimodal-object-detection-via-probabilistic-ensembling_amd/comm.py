@@ -39,6 +39,12 @@ def get_rank():
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
 
+def is_distributed():
+    """A process group exists - also a ONE-rank one (PROBEN_FORCE_DIST=1 under a launcher: how the RCCL code path is executed
+    on a one-GPU box; the collectives then run for real instead of taking the world-size-1 shortcut)."""
+    return dist.is_available() and dist.is_initialized()
+
+
 def is_main_process():
     return get_rank() == 0
 
@@ -60,7 +66,7 @@ def shard_range(num_items, rank=None, world=None):
 def all_gather_rows(rows, group=None):
     """rows: [n, C] tensor (any n per rank).  Returns [sum n, C] on every rank, rank order preserved."""
     world = get_world_size()
-    if world == 1:
+    if not is_distributed():
         return rows
     n = torch.tensor([rows.shape[0]], dtype=torch.int32, device=rows.device)
     counts = [torch.zeros_like(n) for _ in range(world)]
@@ -77,7 +83,7 @@ def all_gather_rows(rows, group=None):
 def all_gather_padded(t, group=None):
     """Fixed-shape tensor per rank -> [W, ...] (no host sync: used inside the timed bench step)."""
     world = get_world_size()
-    if world == 1:
+    if not is_distributed():
         return t.unsqueeze(0)
     out = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
     dist.all_gather_into_tensor(out.view(-1), t.contiguous().view(-1), group=group)
@@ -113,7 +119,7 @@ def gather_rows(rows):
     The payload crosses ranks as ONE padded tensor all-gather on the rank's device (RCCL over xGMI for CUDA ranks) - the
     reference pickles per-image dict lists through gloo (evaluation/FLIR_evaluation.py:124-131)."""
     t = torch.as_tensor(rows)
-    if get_world_size() == 1:
+    if not is_distributed():
         return t.cpu()
     dev = _DEVICE if _DEVICE is not None else t.device
     return all_gather_rows(t.to(dev).contiguous()).cpu()

@@ -281,7 +281,7 @@ class FLIREvaluator:
                 {"image_id": int(r[0]), "category_id": int(r[6]), "bbox": [r[1], r[2], r[3], r[4]], "score": float(r[5])}]})
 
     def evaluate(self, out_eval_path=""):
-        if self._distributed and comm.get_world_size() > 1:
+        if self._distributed and comm.is_distributed():
             # The reference gathers pickled per-image dict lists to rank 0 (FLIR_evaluation.py:124-131, comm.gather over gloo).
             # Here a rank's predictions are [n, 7] float64 rows (image_id, x, y, w, h, score, category_id) - exact images of
             # the float32 detector outputs - and ONE padded all-gather on the rank's device moves them (RCCL over xGMI);

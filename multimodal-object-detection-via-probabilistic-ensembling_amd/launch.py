@@ -79,7 +79,9 @@ def init_distributed(device="cuda", expect_world=None):
         torch.cuda.set_device(local)
     if expect_world is not None and expect_world > 1 and world != expect_world:
         sys.exit(f"--world-size {expect_world} but the launcher started {world} rank(s)")
-    if world > 1:
+    # PROBEN_FORCE_DIST=1: build the group even for ONE rank under a launcher - RCCL initialises a communicator and runs the
+    # drivers' collectives for real (comm.is_distributed()); how the nccl code path is executed on a one-GPU box
+    if world > 1 or (os.environ.get("PROBEN_FORCE_DIST") == "1" and under_launcher()):
         import torch.distributed as dist
         if not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -1,0 +1,13 @@
+import os, torch, torch.distributed as dist
+rank=int(os.environ["RANK"]); world=int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0)
+try:
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda",0))
+    x=torch.full((4,),float(rank),device="cuda")
+    out=torch.empty((world*4,),device="cuda")
+    dist.all_gather_into_tensor(out,x)
+    torch.cuda.synchronize()
+    print("rank",rank,"ok",out.tolist(), flush=True)
+    dist.destroy_process_group()
+except Exception as e:
+    print("rank",rank,"FAILED",repr(e)[:300], flush=True)

@@ -98,3 +98,36 @@ def test_world_size_2_kaist_rows_are_byte_identical(tmp_path):
                                      "--out_folder", str(out), "--batch", "2", "--world-size", str(world)], env)
             blobs[world] = open(out / f"KAIST_{method}_result.txt", "rb").read()
         assert blobs[1] == blobs[2] and blobs[1].count(b"\n") > 5, method
+
+
+def test_one_rank_rccl_group_runs_the_nccl_code_path(tmp_path):
+    """RCCL refuses two ranks on one device, so on a one-GPU box the two-rank tests above use gloo.  This test puts RCCL itself
+    under the drivers: ONE rank under the launcher with PROBEN_FORCE_DIST=1 -> init_process_group("nccl") builds a communicator,
+    the evaluator's row gather and bench.py's per-step all_gather_into_tensor run as RCCL collectives on device tensors
+    (NCCL_DEBUG=VERSION makes the library announce itself), and the results equal the plain single-process run."""
+    import proben_amd  # noqa: F401
+    from proben_amd import launch
+    from test_boundary_gpu import _write_flir
+    root = tmp_path / "val"
+    _write_flir(root, 5, 256, 320)
+    env = _env(True)
+    plain = tmp_path / "plain"
+    _cli("demo_mAP_FLIR", ["--dataset_path", str(root), "--fusion_method", "thermal_only", "--outfolder", str(plain), "--dataset_name", "flir_plain"], env)
+    env["PROBEN_FORCE_DIST"] = "1"
+    env["NCCL_DEBUG"] = "VERSION"
+    forced = tmp_path / "forced"
+    argv = ["--dataset_path", str(root), "--fusion_method", "thermal_only", "--outfolder", str(forced), "--dataset_name", "flir_forced"]
+    p = subprocess.run(launch.launch_command(argv, 1, launch.free_port(), module="proben_amd.cli.demo_mAP_FLIR"), capture_output=True, text=True,
+                       env=env, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    assert "RCCL version" in (p.stdout + p.stderr), "RCCL did not initialise"      # "RCCL version : 2.26.6-..." (NCCL_DEBUG=VERSION)
+    a, b = json.load(open(plain / "FLIR_mAP_results.json")), json.load(open(forced / "FLIR_mAP_results.json"))
+    assert a["results"] == b["results"]
+    assert json.load(open(plain / "coco_instances_results.json")) == json.load(open(forced / "coco_instances_results.json"))
+    # bench.py: the per-step all-gather of the fused rows over the one-rank RCCL group
+    args = ["--gpus", "1", "--steps", "3", "--warmup", "1", "--batch", "4", "--depth", "50", "--no-cpu-baseline", "--no-roofline", "--no-micro"]
+    p = subprocess.run(launch.launch_command(args, 1, launch.free_port(), script=os.path.join(ROOT, "bench.py")), capture_output=True, text=True,
+                       env=env, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and "all_gather_into_tensor" in line["config"]["collective"] and line["value"] > 0
