@@ -7,24 +7,25 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float float16v __attribute__((ext_vector_type(16)));
 struct Args { const _Float16* wts; const _Float16* pix; float* sink; int iters; };
 
-template <int TPX, int D, int WPS>
+template <int TPX, int D, int WPS, int CB = 2>
 __global__ __launch_bounds__(256, WPS) void probe(Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     for (int i = threadIdx.x; i < 4096; i += 256) reinterpret_cast<half8*>(smem)[i] = reinterpret_cast<const half8*>(a.pix)[i];
     __syncthreads();
-    float16v acc[2 * TPX];
+    float16v acc[CB * TPX];
 #pragma unroll
-    for (int i = 0; i < 2 * TPX; ++i)
+    for (int i = 0; i < CB * TPX; ++i)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.wts), 0, 1 << 22, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.wts), 0, 1 << 23, 0x00020000);
     const unsigned char* fb = smem + (lane & 31) * 144 + (lane >> 5) * 16;
-    half8 wf[D][2], pf[2][TPX];
+    half8 wf[D][CB], pf[2][TPX];
 #pragma unroll
     for (int d = 0; d < D; ++d) {
-        wf[d][0] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16, (w * 64 + d) * 2048, 0));
-        wf[d][1] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16 + 1024, (w * 64 + d) * 2048, 0));
+#pragma unroll
+        for (int c = 0; c < CB; ++c)
+            wf[d][c] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16 + c * 1024, (w * 64 + d) * 1024 * CB, 0));
     }
 #pragma unroll
     for (int i = 0; i < TPX; ++i) pf[0][i] = *reinterpret_cast<const half8*>(fb + i * 32 * 144);
@@ -34,50 +35,52 @@ __global__ __launch_bounds__(256, WPS) void probe(Args a) {
 #pragma unroll
             for (int i = 0; i < TPX; ++i) pf[(t + 1) & 1][i] = *reinterpret_cast<const half8*>(fb + i * 32 * 144 + ((t + 1) & 3) * 32);
 #pragma unroll
-            for (int blk = 0; blk < 2; ++blk)
+            for (int blk = 0; blk < CB; ++blk)
 #pragma unroll
                 for (int i = 0; i < TPX; ++i)
                     acc[blk * TPX + i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[t][blk], pf[t & 1][i], acc[blk * TPX + i], 0, 0, 0);
-            const int so = (w * 64 + ((it + t + D) & 63)) * 2048;
-            wf[t][0] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16, so, 0));
-            wf[t][1] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16 + 1024, so, 0));
+            const int so = (w * 64 + ((it + t + D) & 63)) * 1024 * CB;
+#pragma unroll
+            for (int c = 0; c < CB; ++c)
+                wf[t][c] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16 + c * 1024, so, 0));
 #pragma unroll
             for (int i = 0; i < TPX; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, TPX - 2, 0);
+#pragma unroll
+            for (int c = 0; c < CB; ++c) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, CB * TPX - TPX - CB, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < 2 * TPX; ++i) s += acc[i][0] + acc[i][7];
+    for (int i = 0; i < CB * TPX; ++i) s += acc[i][0] + acc[i][7];
     if (s == 12345.678f) a.sink[0] = s;
 }
 
-template <int TPX, int D, int WPS>
+template <int TPX, int D, int WPS, int CB = 2>
 void run(Args a, int blocks_per_cu, const char* name) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    hipFuncSetAttribute((const void*)probe<TPX, D, WPS>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
+    hipFuncSetAttribute((const void*)probe<TPX, D, WPS, CB>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
     float best = 1e30f;
     for (int r = 0; r < 4; ++r) {
         hipEventRecord(e0);
-        hipLaunchKernelGGL((probe<TPX, D, WPS>), dim3(256 * blocks_per_cu), dim3(256), 72 * 1024, 0, a);
+        hipLaunchKernelGGL((probe<TPX, D, WPS, CB>), dim3(256 * blocks_per_cu), dim3(256), 72 * 1024, 0, a);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         if (r && ms < best) best = ms;
     }
-    const double fl = 2.0 * 32 * 32 * 16 * 2.0 * TPX * a.iters * 4 * 256 * blocks_per_cu;
+    const double fl = 2.0 * 32 * 32 * 16 * (double)CB * TPX * a.iters * 4 * 256 * blocks_per_cu;
     printf("%-44s %8.3f ms %8.0f TFLOP/s\n", name, best, fl / best / 1e9);
 }
 
 int main() {
-    std::vector<_Float16> hw(1 << 21), hp(32768);
+    std::vector<_Float16> hw(1 << 22), hp(32768);
     srand(1);
     auto nrm = [] { float s = 0; for (int i = 0; i < 12; ++i) s += rand() / (float)RAND_MAX; return s - 6.f; };
     for (auto& x : hw) x = (_Float16)(nrm() / 48.f);
@@ -93,5 +96,8 @@ int main() {
     run<8, 4, 1>(a, 1, "TPX 8, depth 4, 1 wave / SIMD");
     run<8, 8, 1>(a, 1, "TPX 8, depth 8, 1 wave / SIMD");
     run<6, 4, 1>(a, 1, "TPX 6, depth 4, 1 wave / SIMD");
+    run<4, 4, 1, 4>(a, 1, "128 px x 128 ch per wave (TPX 4, 4 channel blocks), 1 wave / SIMD");
+    run<4, 8, 1, 4>(a, 1, "128 px x 128 ch per wave, depth 8");
+    run<2, 4, 2, 4>(a, 2, "64 px x 128 ch per wave (TPX 2, 4 channel blocks), 2 waves / SIMD");
     return 0;
 }
