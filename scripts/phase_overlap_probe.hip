@@ -247,6 +247,17 @@ int main(int argc, char** argv) {
     a.wts = dw; a.pix = dp; a.rd = rd; a.wr = wr; a.sink = sink;
     a.mem_iters = ntiles;
     const double mem_bytes = 2.0 * span;
+    if (argc > 2) {   // PMC mode (rocprofv3 --pmc ...): six dispatches in a fixed order, one launch each, no timing loops
+        // 0: matrix alone (full diet)  1: memory alone  2: both (full diet)  3: matrix alone (no weight loads)  4: both (no weight loads)  5: phase-locked
+        a.mat_iters = atoi(argv[2]);
+        const int seq[6][2] = {{1, 0}, {2, 0}, {3, 0}, {1, 1}, {3, 1}, {4, 0}};
+        for (auto& m : seq) {
+            a.mode = m[0]; a.variant = m[1];
+            hipLaunchKernelGGL(probe, dim3(256), dim3(512), 72 * 1024, 0, a);
+            hipDeviceSynchronize();
+        }
+        return 0;
+    }
     a.mat_iters = 4096; a.mode = 1;
     float t_mat = run(a, 4);
     a.mode = 2;
