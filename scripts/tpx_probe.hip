@@ -5,7 +5,7 @@
 #include <vector>
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float float16v __attribute__((ext_vector_type(16)));
-struct Args { const _Float16* wts; const _Float16* pix; float* sink; int iters; };
+struct Args { const _Float16* wts; const _Float16* pix; float* sink; int iters; int rotate; };
 
 template <int TPX, int D, int WPS, int CB = 2>
 __global__ __launch_bounds__(256, WPS) void probe(Args a) {
@@ -20,12 +20,13 @@ __global__ __launch_bounds__(256, WPS) void probe(Args a) {
         for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.wts), 0, 1 << 23, 0x00020000);
     const unsigned char* fb = smem + (lane & 31) * 144 + (lane >> 5) * 16;
+    const int rot = a.rotate ? (blockIdx.x * 5) & 63 : 0;     // rotate: every CU starts its walk through the weight ring somewhere else
     half8 wf[D][CB], pf[2][TPX];
 #pragma unroll
     for (int d = 0; d < D; ++d) {
 #pragma unroll
         for (int c = 0; c < CB; ++c)
-            wf[d][c] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16 + c * 1024, (w * 64 + d) * 1024 * CB, 0));
+            wf[d][c] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16 + c * 1024, (w * 64 + ((d + rot) & 63)) * 1024 * CB, 0));
     }
 #pragma unroll
     for (int i = 0; i < TPX; ++i) pf[0][i] = *reinterpret_cast<const half8*>(fb + i * 32 * 144);
@@ -39,7 +40,7 @@ __global__ __launch_bounds__(256, WPS) void probe(Args a) {
 #pragma unroll
                 for (int i = 0; i < TPX; ++i)
                     acc[blk * TPX + i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[t][blk], pf[t & 1][i], acc[blk * TPX + i], 0, 0, 0);
-            const int so = (w * 64 + ((it + t + D) & 63)) * 1024 * CB;
+            const int so = (w * 64 + ((it + t + D + rot) & 63)) * 1024 * CB;
 #pragma unroll
             for (int c = 0; c < CB; ++c)
                 wf[t][c] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16 + c * 1024, so, 0));
@@ -92,6 +93,10 @@ int main() {
     hipMalloc(&sink, 4);
     a.wts = dw; a.pix = dp; a.sink = sink; a.iters = 4096;
     run<4, 4, 2>(a, 2, "TPX 4, depth 4, 2 waves / SIMD (shipped diet)");
+    a.rotate = 1;
+    run<4, 4, 2>(a, 2, "  same, every CU at a different ring position");
+    run<8, 4, 1>(a, 1, "  TPX 8, 1 wave / SIMD, CUs at different positions");
+    a.rotate = 0;
     run<4, 4, 2>(a, 1, "TPX 4, depth 4, 1 wave / SIMD");
     run<8, 4, 1>(a, 1, "TPX 8, depth 4, 1 wave / SIMD");
     run<8, 8, 1>(a, 1, "TPX 8, depth 8, 1 wave / SIMD");
