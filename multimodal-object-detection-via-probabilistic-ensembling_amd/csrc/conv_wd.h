@@ -172,22 +172,15 @@ __global__ __launch_bounds__(64 * WM * WN, (TPX <= 4 ? 2 : 1)) void conv3x3_wd_k
         wf[slot][1] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16 + 1024, so, 0));
     };
 
-    // ---- accumulators, initialised with the bias: lane holds channels n0 + wn*64 + (lane>>5)*32 + blk*16 + r ----
+    // ---- accumulators start at zero; the bias is added in the epilogue (conv_wd9.h, which takes the large launches of the same
+    // layers, sums in the same order: results must not depend on which of the two kernels a batch size selects) ----
     float16v acc[2][TPX];
-    {
-        const float* bp = a.bias + n0 + wn * 64 + (lane >> 5) * 32;
 #pragma unroll
-        for (int blk = 0; blk < 2; ++blk) {
-            float16v b;
+    for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-                const float4 v = *reinterpret_cast<const float4*>(bp + blk * 16 + r4 * 4);
-                b[r4 * 4 + 0] = v.x; b[r4 * 4 + 1] = v.y; b[r4 * 4 + 2] = v.z; b[r4 * 4 + 3] = v.w;
-            }
+        for (int i = 0; i < TPX; ++i)
 #pragma unroll
-            for (int i = 0; i < TPX; ++i) acc[blk][i] = b;
-        }
-    }
+            for (int r = 0; r < 16; ++r) acc[blk][i][r] = 0.f;
 
     // ---- prologue: slabs 0 and 1 into the ring, weight ring primed ----
 #pragma unroll
@@ -263,7 +256,24 @@ __global__ __launch_bounds__(64 * WM * WN, (TPX <= 4 ? 2 : 1)) void conv3x3_wd_k
         cur = nxt;
     }
 
-    // ---- epilogue: ReLU + fp16, 64 contiguous bytes per lane and pixel block ----
+    // ---- epilogue: + bias (lane holds channels n0 + wn*64 + (lane>>5)*32 + blk*16 + r), ReLU, fp16, 64 contiguous bytes per lane
+    // and pixel block ----
+    {
+        const float* bp = a.bias + n0 + wn * 64 + (lane >> 5) * 32;
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            float16v b;
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const float4 v = *reinterpret_cast<const float4*>(bp + blk * 16 + r4 * 4);
+                b[r4 * 4 + 0] = v.x; b[r4 * 4 + 1] = v.y; b[r4 * 4 + 2] = v.z; b[r4 * 4 + 3] = v.w;
+            }
+#pragma unroll
+            for (int i = 0; i < TPX; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[blk][i][r] += b[r];
+        }
+    }
     if (a.relu || HEAD) {
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk)

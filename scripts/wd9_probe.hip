@@ -1,0 +1,146 @@
+// Development harness for the persistent one-wave-per-SIMD weights-direct 3x3 kernel (csrc/conv_wd9.h): shipped TPX = 4 kernel vs
+// wd9 builds on the network's 3x3 shapes - sampled fp64 check, bit comparison against the shipped kernel, timing, ablations and
+// an s_memtime timeline of one workgroup.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -I include -I multimodal-object-detection-via-probabilistic-ensembling_amd/csrc \
+//         scripts/wd9_probe.hip -o scripts/wd9_probe && scripts/wd9_probe [first shape] [last shape]
+#include "conv_wd9.h"
+
+#include <cmath>
+#include <cstdlib>
+#include <random>
+#include <vector>
+
+namespace pe {
+void set_error(const char*, ...) {}
+int ensure_dynamic_lds(const void* k, size_t bytes, const char*) {
+    return hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess ? 0 : -1;
+}
+}  // namespace pe
+
+static std::vector<_Float16> g_ref;   // output of the shipped kernel (bit reference)
+
+template <typename Launch>
+void run_variant(const char* name, Launch launch, pe::ConvWdArgs a, const std::vector<_Float16>& hin, const std::vector<_Float16>& hw,
+                 const std::vector<float>& hb, std::vector<_Float16>& hout, int reps, bool is_ref, bool check) {
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipMemset(a.out, 0xff, (size_t)a.M * a.out_stride * 2);
+    int st = launch(a);
+    hipError_t err = hipDeviceSynchronize();
+    if (st != 0 || err != hipSuccess) { printf("%-34s unsupported/failed (%d, %s)\n", name, st, hipGetErrorString(err)); return; }
+    int bad = 0; long long diff = -1; double max_err = 0;
+    if (check) {
+        hipMemcpy(hout.data(), a.out, hout.size() * 2, hipMemcpyDeviceToHost);
+        std::mt19937 rng(7);
+        const int K = 9 * a.Cin;
+        for (int s = 0; s < 3000; ++s) {
+            int m, c;
+            if (s < 1000) {   // image borders / tile seams / the last tile
+                const int n = (s & 4) ? a.N - 1 : rng() % a.N, hh = (s & 1) ? (rng() % 2 ? 0 : a.H - 1) : rng() % a.H, ww = (s & 2) ? (rng() % 2 ? 0 : a.W - 1) : rng() % a.W;
+                m = (n * a.H + hh) * a.W + ww;
+            } else m = rng() % a.M;
+            c = rng() % a.Cout;
+            const int ow = m % a.W, oh = (m / a.W) % a.H, n = m / (a.W * a.H);
+            double ref = hb[c];
+            for (int kh = 0; kh < 3; ++kh)
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int ih = oh + kh - 1, iw = ow + kw - 1;
+                    if (ih < 0 || ih >= a.H || iw < 0 || iw >= a.W) continue;
+                    const _Float16* x = &hin[((size_t)(n * a.H + ih) * a.W + iw) * a.Cin];
+                    const _Float16* w = &hw[(size_t)c * K + (kh * 3 + kw) * a.Cin];
+                    for (int ci = 0; ci < a.Cin; ++ci) ref += (double)(float)x[ci] * (double)(float)w[ci];
+                }
+            if (a.relu && ref < 0) ref = 0;
+            const double got = (float)hout[(size_t)m * a.out_stride + c];
+            const double e = fabs(got - ref);
+            if (e > max_err) max_err = e;
+            if (!(e <= 2e-2 + 4e-3 * fabs(ref))) ++bad;
+        }
+        if (is_ref) g_ref = hout;
+        else if (g_ref.size() == hout.size()) {
+            diff = 0;
+            for (size_t i = 0; i < hout.size(); ++i) diff += memcmp(&hout[i], &g_ref[i], 2) != 0;
+        }
+    }
+    for (int i = 0; i < 2; ++i) launch(a);
+    hipEventRecord(e0);
+    for (int i = 0; i < reps; ++i) launch(a);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    ms /= reps;
+    const double tf = 2.0 * a.M * a.Cout * 9 * a.Cin / (ms * 1e-3) / 1e12;
+    if (check) printf("%-34s %8.4f ms %8.1f TFLOP/s   check: %d bad / 3000, max err %.4f, halfs differing from shipped: %lld\n", name, ms, tf, bad, max_err, diff);
+    else printf("%-34s %8.4f ms %8.1f TFLOP/s\n", name, ms, tf);
+    fflush(stdout);
+}
+
+int main(int argc, char** argv) {
+    struct Shape { int N, H, W, Cin, Cout; };
+    const Shape shapes[] = {{3, 16, 64, 64, 256},     // tiny: tile seams, image borders, ragged last tile
+                            {5, 25, 32, 256, 256},    // W = 32, tile = 8 rows, ragged
+                            {32, 200, 256, 256, 256}, // p2
+                            {32, 100, 128, 256, 256}, // p3
+                            {32, 50, 64, 256, 256},   // res4 conv2 / p4
+                            {32, 25, 32, 512, 512}};  // res5 conv2
+    const int first = argc > 1 ? atoi(argv[1]) : 0, last = argc > 2 ? atoi(argv[2]) : 5;
+    unsigned long long* dbg; hipMalloc(&dbg, 256 * 128 * 8);
+    for (int si = first; si <= last; ++si) {
+        const Shape s = shapes[si];
+        const int M = s.N * s.H * s.W, K = 9 * s.Cin;
+        std::vector<_Float16> hin((size_t)M * s.Cin), hw((size_t)s.Cout * K), hout((size_t)M * s.Cout);
+        std::vector<float> hb(s.Cout);
+        std::mt19937 rng(3 + si);
+        std::normal_distribution<float> nd(0.f, 1.f);
+        for (auto& v : hin) { const float x = nd(rng); v = (_Float16)(x > 0 ? x : 0.f); }
+        const float wsc = 1.f / sqrtf((float)K);
+        for (auto& v : hw) v = (_Float16)(nd(rng) * wsc);
+        for (auto& v : hb) v = nd(rng) * 0.1f;
+        _Float16 *din, *dw, *dwp, *dout; float* db;
+        hipMalloc(&din, hin.size() * 2); hipMalloc(&dw, hw.size() * 2); hipMalloc(&dwp, hw.size() * 2);
+        hipMalloc(&dout, hout.size() * 2); hipMalloc(&db, hb.size() * 4);
+        hipMemcpy(din, hin.data(), hin.size() * 2, hipMemcpyHostToDevice);
+        hipMemcpy(dw, hw.data(), hw.size() * 2, hipMemcpyHostToDevice);
+        hipMemcpy(db, hb.data(), hb.size() * 4, hipMemcpyHostToDevice);
+        pe::ConvWdArgs a{};
+        a.in = din; a.bias = db; a.res = nullptr; a.out = dout; a.N = s.N; a.H = s.H; a.W = s.W; a.Cin = s.Cin; a.Cout = s.Cout;
+        a.M = M; a.relu = 1; a.out_stride = s.Cout;
+        printf("--- 3x3 N%d %dx%d %d->%d (%.1f GFLOP)\n", s.N, s.H, s.W, s.Cin, s.Cout, 2.0 * M * s.Cout * K / 1e9);
+        const int reps = si == 2 ? 5 : 20;
+        const long long total = (long long)(s.Cout / 32) * (K / 16) * 64;
+        hipLaunchKernelGGL(wd::pack_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, 0, dw, dwp, s.Cout, K, s.Cin, 4, 1);
+        a.wpk = dwp;
+        g_ref.clear();
+        run_variant("shipped wd<1,4,tpx4,d4>", [](pe::ConvWdArgs x) { return wd::launch_conv3x3_wd<1, 4, 4, 4>(x, 0); }, a, hin, hw, hb, hout, reps, true, true);
+        run_variant("wd9 tpx8 d4", [](pe::ConvWdArgs x) { return wd9::launch<8, 4>(x, 0); }, a, hin, hw, hb, hout, reps, false, true);
+        run_variant("wd9 tpx8 d6", [](pe::ConvWdArgs x) { return wd9::launch<8, 6>(x, 0); }, a, hin, hw, hb, hout, reps, false, true);
+        run_variant("  wd9 d4 abl: no stores", [](pe::ConvWdArgs x) { return wd9::launch<8, 4, 1>(x, 0); }, a, hin, hw, hb, hout, reps, false, false);
+        run_variant("  wd9 d4 abl: no slab DMA", [](pe::ConvWdArgs x) { return wd9::launch<8, 4, 2>(x, 0); }, a, hin, hw, hb, hout, reps, false, false);
+        run_variant("  wd9 d4 abl: no weight loads", [](pe::ConvWdArgs x) { return wd9::launch<8, 4, 4>(x, 0); }, a, hin, hw, hb, hout, reps, false, false);
+        run_variant("  wd9 d4 abl: none of them", [](pe::ConvWdArgs x) { return wd9::launch<8, 4, 7>(x, 0); }, a, hin, hw, hb, hout, reps, false, false);
+        if (s.W <= 64) {
+            run_variant("wd9 tpx6 d4", [](pe::ConvWdArgs x) { return wd9::launch<6, 4>(x, 0); }, a, hin, hw, hb, hout, reps, false, true);
+            run_variant("wd9 tpx4 d4 (1 wave/SIMD)", [](pe::ConvWdArgs x) { return wd9::launch<4, 4>(x, 0); }, a, hin, hw, hb, hout, reps, false, true);
+        }
+        if (si >= 2 && si <= 4) {   // timeline of three workgroups (cycles, s_memtime)
+            hipMemset(dbg, 0, 256 * 128 * 8);
+            wd9::launch<8, 4, 0, 1>(a, 0, 256, dbg);
+            hipDeviceSynchronize();
+            std::vector<unsigned long long> h(256 * 128);
+            hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost);
+            unsigned long long t0 = ~0ull;
+            for (int b = 0; b < 256; ++b) if (h[b * 128] && h[b * 128] < t0) t0 = h[b * 128];
+            for (int b : {0, 1, 100}) {
+                printf("  timeline wg %d: start %llu |", b, h[b * 128] - t0);
+                for (int j = 0; j < 6 && h[b * 128 + 1 + j * 3]; ++j)
+                    printf(" tile%d loop %llu epi %llu gap %llu |", j, h[b * 128 + 2 + j * 3] - h[b * 128 + 1 + j * 3], h[b * 128 + 3 + j * 3] - h[b * 128 + 2 + j * 3],
+                           j ? h[b * 128 + 1 + j * 3] - h[b * 128 + 3 + (j - 1) * 3] : h[b * 128 + 1] - h[b * 128]);
+                printf("\n");
+            }
+            // spread of tile-end times over the workgroups (do they finish tiles in lockstep?)
+            unsigned long long lo = ~0ull, hi = 0;
+            for (int b = 0; b < 256; ++b) { const unsigned long long e = h[b * 128 + 2]; if (e) { lo = e < lo ? e : lo; hi = e > hi ? e : hi; } }
+            printf("  first-tile loop end: min %llu max %llu after the earliest start\n", lo - t0, hi - t0);
+        }
+        hipFree(din); hipFree(dw); hipFree(dwp); hipFree(dout); hipFree(db);
+    }
+    return 0;
+}
