@@ -20,7 +20,11 @@ ARCH = "gfx950"
 
 # Per-source extra flags.  The detection post-ops and ProbEn take discrete decisions on
 # IoU / score thresholds, so they must round like the reference's separate mul/add/div.
-EXTRA = {"default": ["-ffp-contract=off"], "conv_igemm.hip": [], "conv_igemm2.hip": [], "conv_wd.hip": [], "bneck64.hip": [], "stem.hip": []}
+# conv_wd9.hip: its asm statements own the accumulation registers a[0:255] - the compiler must not spill VGPRs into them - and its
+# epilogue's scalar fp32 adds must stay scalar (tests/test_build_audit.py audits the emitted code).
+WD9_FLAGS = ["-fno-slp-vectorize", "-mllvm", "-amdgpu-spill-vgpr-to-agpr=0"]
+EXTRA = {"default": ["-ffp-contract=off"], "conv_igemm.hip": [], "conv_igemm2.hip": [], "conv_wd.hip": [], "bneck64.hip": [], "stem.hip": [],
+         "conv_wd9.hip": WD9_FLAGS}
 
 
 def hipcc():

@@ -471,7 +471,7 @@ __global__ __launch_bounds__(64 * WM * WN, (TPX <= 4 ? 2 : 1)) void conv3x3_wd_k
 
 // conv3 weights [tail_cout][256] fp16 -> fragment records in the tail phase's stream order:
 // record (wn, c, ks, blk), lane l: output = wn*(NCH*64) + c*64 + cout_perm(blk, l & 31), 8 halfs = k ks*16 + (l>>5)*8 + e
-__global__ void pack_tail_kernel(const _Float16* w, _Float16* out, int tail_cout) {
+static __global__ void pack_tail_kernel(const _Float16* w, _Float16* out, int tail_cout) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;     // one thread per lane slot
     const int NCH = tail_cout / 256;
     if (idx >= 4 * NCH * 16 * 2 * 64) return;
@@ -489,7 +489,7 @@ __global__ void pack_tail_kernel(const _Float16* w, _Float16* out, int tail_cout
 
 // head weights [rows <= 16][256] fp16 -> A fragments in the K order the accumulator layout dictates:
 // record (wn, j), lane l: row = l & 31 (rows >= `rows` are zero), 8 halfs = channels wn*64 + (l>>5)*32 + j*8 + e
-__global__ void pack_head_kernel(const _Float16* w, _Float16* out, int rows, int C) {
+static __global__ void pack_head_kernel(const _Float16* w, _Float16* out, int rows, int C) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;     // one thread per lane slot: 4 wn x 4 j x 64 lanes
     if (idx >= 4 * 4 * 64) return;
     const int lane = idx & 63, j = (idx >> 6) & 3, wn = idx >> 8;
@@ -504,7 +504,7 @@ __global__ void pack_head_kernel(const _Float16* w, _Float16* out, int rows, int
 }
 
 // packing: [Cout][3][3][Cin] (or [Cout][K] for 1x1 with order = 0) -> fragment records
-__global__ void pack_weights_kernel(const _Float16* w, _Float16* out, int Cout, int K, int Cin, int WN, int is3x3) {
+static __global__ void pack_weights_kernel(const _Float16* w, _Float16* out, int Cout, int K, int Cin, int WN, int is3x3) {
     // one thread per 16-byte lane slot
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int KSEQ = K / 16;

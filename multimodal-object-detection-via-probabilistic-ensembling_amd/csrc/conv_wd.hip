@@ -1,6 +1,10 @@
 // C-ABI of the weights-direct convolution kernels (csrc/conv_wd.h): packing, support query, launch.
 #include "conv_wd.h"
 
+namespace pe {
+int wd9_conv3x3(ConvWdArgs a, hipStream_t st);   // csrc/conv_wd9.hip: the large launches of the same layers, same bits
+}
+
 namespace {
 
 // channel split of a block: WN waves x 64 output channels
@@ -46,7 +50,9 @@ extern "C" int pe_conv3x3_wd_f16(const void* input, const void* packed_weight, c
     a.in = (const _Float16*)input; a.wpk = (const _Float16*)packed_weight; a.bias = bias; a.res = nullptr;
     a.out = (_Float16*)output; a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.M = (int)M; a.relu = relu;
     a.out_stride = os;
-    const int st = wd::launch_conv3x3_wd<1, 4, 4, 4>(a, (hipStream_t)stream);
+    PE_CHECK_ARG(M * os * 2 < (1ll << 32), "pe_conv3x3_wd_f16: output window larger than 4 GiB (32-bit buffer offsets)");
+    int st = pe::wd9_conv3x3(a, (hipStream_t)stream);
+    if (st == PE_ERR_UNSUPPORTED) st = wd::launch_conv3x3_wd<1, 4, 4, 4>(a, (hipStream_t)stream);
     if (st != PE_OK) {
         pe::set_error("pe_conv3x3_wd_f16: unsupported geometry");
         return st;

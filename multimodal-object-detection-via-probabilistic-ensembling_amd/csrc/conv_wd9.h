@@ -45,13 +45,13 @@ struct Geo {
     static constexpr int BPX = TPX * 32;           // pixels per tile (whole image rows)
     static constexpr int NSEG = BPX / SEG;
     static constexpr int SEGP = SEG + 16;          // entries per segment: halo, SEG pixels, halo, 14 never-read pad entries
-    static constexpr int E = NSEG * SEGP;
+    static constexpr int E = (NSEG * SEGP + 31) / 32 * 32;   // entries incl. never-read padding: every wave moves whole 1 KiB pieces
     static constexpr int SLAB = E * 128;           // bytes per ring slot
-    static constexpr int NPIECE = E / 8;           // 1 KiB DMA pieces per slab
+    static constexpr int NPIECE = E / 8;           // 1 KiB pieces per slab, a multiple of 4
     static constexpr int PPW = (NPIECE + 3) / 4;   // pieces per wave and group, one per K-step
     static_assert(BPX % SEG == 0 && SEG >= 32 && NSEG >= 1, "tiles are whole image rows");
     static_assert(PPW <= 11, "one DMA piece per K-step, K-steps 0 .. 10 (the group's barrier sits in front of K-step 11)");
-    static_assert(3 * SLAB <= 160 * 1024, "three ring slots must fit the CU's LDS");
+    static_assert(3 * SLAB + 16384 <= 160 * 1024, "three ring slots + the epilogue patches must fit the CU's LDS");
 };
 
 // ---- the accumulator file: a[LO : LO + 15] = accumulator block (blk, i) with LO = (blk * TPX + i) * 16 ----
@@ -111,12 +111,17 @@ __device__ __forceinline__ void static_for(F&& f) {      // f(ic<0>{}), ..., f(i
     static_for_impl<0, N>(f);
 }
 
-// ABL (measurement builds, results wrong): 1 = no output stores, 2 = no slab DMA, 4 = no weight loads in the loop
+// VAR = SM + 4 * EP.  SM, how the slab reaches LDS: 0 = LDS-DMA issued behind the K-step's fragment reads, 1 = LDS-DMA late in the
+//   K-step (behind accumulator block (1, 4), when the fragment reads have returned), 2 = register-staged (buffer_load a group ahead,
+//   ds_write_b128 in the next group).  EP, the epilogue's stores: 0 = straight from the accumulator layout (a lane owns 64 B of a
+//   pixel: four 16-byte pieces), 1 = through a wave-private LDS patch as whole 128-byte lines.
+// ABL (measurement builds, results wrong): 1 = no output stores, 2 = no slab traffic, 4 = no weight loads in the loop
 // DBG: wave 0 of every workgroup writes s_memtime stamps (kernel start, and per tile: loop start, loop end, epilogue end)
-template <int SEGL, int TPX, int DEPTH, int RELU, int ABL = 0, int DBG = 0>
+template <int SEGL, int TPX, int DEPTH, int RELU, int VAR = 0, int ABL = 0, int DBG = 0>
 __global__ __launch_bounds__(THREADS, 1) void conv3x3_wd9_kernel(pe::ConvWdArgs a, unsigned long long* dbg) {
     using G_ = Geo<SEGL, TPX>;
-    constexpr int SEG = G_::SEG, BPX = G_::BPX, SEGP = G_::SEGP, SLAB = G_::SLAB, NPIECE = G_::NPIECE, PPW = G_::PPW;
+    constexpr int SEG = G_::SEG, BPX = G_::BPX, SEGP = G_::SEGP, SLAB = G_::SLAB, NPIECE = G_::NPIECE, PPW = G_::PPW, NSEG = G_::NSEG;
+    constexpr int SM = VAR & 3, EP = (VAR >> 2) & 1;
     static_assert(12 % DEPTH == 0, "weight prefetch depth must divide the 12 K-steps of a group");
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     typedef __attribute__((address_space(3))) unsigned char lds_byte;
@@ -156,7 +161,7 @@ __global__ __launch_bounds__(THREADS, 1) void conv3x3_wd9_kernel(pe::ConvWdArgs 
         const int c = (lane & 7) ^ ((e >> 1) & 7);
         const int s = e / SEGP, jj = e - s * SEGP - 1;
         sg[k] = s;
-        rel[k] = (q < NPIECE && (unsigned)jj < (unsigned)SEG) ? ((s * SEG + jj) * a.Cin + c * 8) * 2 : -1;
+        rel[k] = (q < NPIECE && s < NSEG && (unsigned)jj < (unsigned)SEG) ? ((s * SEG + jj) * a.Cin + c * 8) * 2 : -1;
     }
     const int4v rin = make_rsrc(a.in, (unsigned)a.M * (unsigned)a.Cin * 2u);
     const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, a.M * a.out_stride * 2, 0x00020000);
@@ -177,9 +182,17 @@ __global__ __launch_bounds__(THREADS, 1) void conv3x3_wd9_kernel(pe::ConvWdArgs 
             badk[k] = (never ? 4 : 0) | (hs == 0 ? 1 : 0) | (hs == a.H - 1 ? 2 : 0);
         }
     };
+    const __amdgpu_buffer_rsrc_t rin_c = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.in), 0, a.M * a.Cin * 2, 0x00020000);
+    half8 sreg[SM == 2 ? PPW : 1];               // SM 2: the pieces of the slab after the next, in flight for a whole group
+    auto piece_off = [&](int k, int shift, int khbits) { return (badk[k] & khbits) ? 0x80000000u : (unsigned)(voffc[k] + shift); };
     auto dma_piece = [&](int k, int slot, int shift, int khbits) {   // shift = ((kh - 1) * W * Cin + cc * 64) * 2, khbits = 4 | (kh == 0) | 2 (kh == 2)
-        const unsigned vo = (badk[k] & khbits) ? 0x80000000u : (unsigned)(voffc[k] + shift);
-        dma16(vo, smem_base + slot * SLAB + (k * 4 + wn) * 1024, rin);
+        dma16(piece_off(k, shift, khbits), smem_base + slot * SLAB + (k * 4 + wn) * 1024, rin);
+    };
+    auto reg_load = [&](int k, int shift, int khbits) {
+        sreg[SM == 2 ? k : 0] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rin_c, piece_off(k, shift, khbits), 0, 0));
+    };
+    auto reg_store = [&](int k, int slot) {
+        *reinterpret_cast<half8*>(smem + slot * SLAB + (k * 4 + wn) * 1024 + lane * 16) = sreg[SM == 2 ? k : 0];
     };
     auto group_shift = [&](int g) { const int cc = g / 3, kh = g - cc * 3; return ((kh - 1) * SEG * a.Cin + cc * 64) * 2; };
     auto group_khbits = [&](int g) { const int kh = g % 3; return 4 | (kh == 0 ? 1 : 0) | (kh == 2 ? 2 : 0); };
@@ -226,10 +239,19 @@ __global__ __launch_bounds__(THREADS, 1) void conv3x3_wd9_kernel(pe::ConvWdArgs 
     // ---- prologue (once per workgroup): slabs 0 and 1 of the first tile, weight ring primed ----
     describe(tile_m0(t_first) >> SEGL);
     if (!(ABL & 2)) {
+        if constexpr (SM == 2) {
 #pragma unroll
-        for (int k = 0; k < PPW; ++k) dma_piece(k, 0, group_shift(0), group_khbits(0));
+            for (int k = 0; k < PPW; ++k) reg_load(k, group_shift(0), group_khbits(0));
 #pragma unroll
-        for (int k = 0; k < PPW; ++k) dma_piece(k, 1, group_shift(1), group_khbits(1));
+            for (int k = 0; k < PPW; ++k) reg_store(k, 0);
+#pragma unroll
+            for (int k = 0; k < PPW; ++k) reg_load(k, group_shift(1), group_khbits(1));      // written to slot 1 during group 0
+        } else {
+#pragma unroll
+            for (int k = 0; k < PPW; ++k) dma_piece(k, 0, group_shift(0), group_khbits(0));
+#pragma unroll
+            for (int k = 0; k < PPW; ++k) dma_piece(k, 1, group_shift(1), group_khbits(1));
+        }
     }
     load_bias(t_first);
 #pragma unroll
@@ -277,12 +299,17 @@ __global__ __launch_bounds__(THREADS, 1) void conv3x3_wd9_kernel(pe::ConvWdArgs 
                     else mfma_acc<i * 16>(wf[slot][0], pf[t & 1][i]);
                     pf[(t + 1) & 1][i] = *reinterpret_cast<const half8*>(src + blk_off(i));
                 });
-                if (!(ABL & 2) && t < PPW) dma_piece(t, nn, l_shift, l_kh);
+                if constexpr (!(ABL & 2) && t < PPW && SM == 0) dma_piece(t, nn, l_shift, l_kh);
+                if constexpr (!(ABL & 2) && t < PPW && SM == 2) {        // slab g + 1 (loaded a group ago) -> its ring slot; slab g + 2 -> registers
+                    reg_store(t, nxt);
+                    reg_load(t, l_shift, l_kh);
+                }
                 static_for<TPX>([&](auto i_) {
                     constexpr int i = decltype(i_)::value;
                     if constexpr (FIRST) mfma_zero<(TPX + i) * 16>(wf[slot][1], pf[t & 1][i]);
                     else mfma_acc<(TPX + i) * 16>(wf[slot][1], pf[t & 1][i]);
                     if constexpr (i == 0) { if (!(ABL & 4)) w_load1(slot, 0, wso); }     // record 0 of the slot: free since (0, TPX - 1)
+                    if constexpr (i == (TPX > 4 ? 4 : TPX - 1) && !(ABL & 2) && t < PPW && SM == 1) dma_piece(t, nn, l_shift, l_kh);
                 });
                 if (!(ABL & 4)) w_load1(slot, 1, wso);                                     // record 1: free since (1, TPX - 1)
             };
@@ -302,7 +329,7 @@ __global__ __launch_bounds__(THREADS, 1) void conv3x3_wd9_kernel(pe::ConvWdArgs 
             // group g - 1, and everything this wave issued since - at least the 22 weight records of this group's K-steps 0 .. 10 -
             // may stay in flight.  All reads of slab g (the last were step 11's fragments, read in step 10) are behind the barrier's
             // lgkmcnt(0), so group g + 1 may overwrite its slot with slab g + 3.
-            asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
+            if constexpr (SM != 2) asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
             __syncthreads();
             kstep(ic<11>{}, std::false_type{});
             cur = nxt;
@@ -314,18 +341,47 @@ __global__ __launch_bounds__(THREADS, 1) void conv3x3_wd9_kernel(pe::ConvWdArgs 
             const int m0 = tile_m0(tile), n0 = (tile % a.tiles_n) * (WN * 64);
             const unsigned ob = (unsigned)(((m0 + (lane & 31)) * a.out_stride + n0 + wn * 64 + (lane >> 5) * 32) * 2);
             asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7");      // the last MFMAs' results must have reached the register file
-            static_for<TPX * 4>([&](auto q_) {
-                constexpr int q = decltype(q_)::value, i = q >> 2, blk = (q >> 1) & 1, hh = q & 1;
-                float x[8];
-                acc_read8<(blk * TPX + i) * 16 + hh * 8>(x);
-                half8 v;
+            if constexpr (EP == 0) {
+                static_for<TPX * 4>([&](auto q_) {
+                    constexpr int q = decltype(q_)::value, i = q >> 2, blk = (q >> 1) & 1, hh = q & 1;
+                    float x[8];
+                    acc_read8<(blk * TPX + i) * 16 + hh * 8>(x);
+                    half8 v;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = (_Float16)(x[e] + bias_v[blk][hh * 8 + e]);
-                if (RELU) v = __builtin_elementwise_maximum(v, (half8)(_Float16)0.f);
-                if (!(ABL & 1))
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4v, v), rout, ob + (blk * 16 + hh * 8) * 2, i * 32 * a.out_stride * 2, 0);
-                else if (v[0] == (_Float16)12345.f) dbg[0] = 1;
-            });
+                    for (int e = 0; e < 8; ++e) v[e] = (_Float16)(x[e] + bias_v[blk][hh * 8 + e]);
+                    if (RELU) v = __builtin_elementwise_maximum(v, (half8)(_Float16)0.f);
+                    if (!(ABL & 1))
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4v, v), rout, ob + (blk * 16 + hh * 8) * 2, i * 32 * a.out_stride * 2, 0);
+                    else if (v[0] == (_Float16)12345.f) dbg[0] = 1;
+                });
+            } else {
+                // a pixel's 64 channels of this wave are one 128-byte line of the output: transpose the pixel block through a
+                // wave-private 4 KiB patch (chunk c of row px in slot c ^ (px & 7)) and store 8 whole lines per instruction
+                unsigned char* patch = smem + 3 * SLAB + wn * 4096;
+                const int px = lane & 31, hq = lane >> 5;
+                const int rrow = lane >> 3, rc = (lane & 7) ^ (rrow & 7);      // read side: row (+ 8 r), the channel chunk that slot lane & 7 holds
+                const unsigned ob2 = (unsigned)(((m0 + rrow) * a.out_stride + n0 + wn * 64 + rc * 8) * 2);
+                static_for<TPX>([&](auto i_) {
+                    constexpr int i = decltype(i_)::value;
+                    static_for<4>([&](auto q_) {
+                        constexpr int q = decltype(q_)::value, blk = q >> 1, hh = q & 1;
+                        float x[8];
+                        acc_read8<(blk * TPX + i) * 16 + hh * 8>(x);
+                        half8 v;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = (_Float16)(x[e] + bias_v[blk][hh * 8 + e]);
+                        if (RELU) v = __builtin_elementwise_maximum(v, (half8)(_Float16)0.f);
+                        *reinterpret_cast<half8*>(patch + px * 128 + (((hq * 4 + blk * 2 + hh) ^ (px & 7)) * 16)) = v;
+                    });
+                    static_for<4>([&](auto r_) {
+                        constexpr int r = decltype(r_)::value;
+                        const half8 v = *reinterpret_cast<const half8*>(patch + (r * 8) * 128 + lane * 16);
+                        if (!(ABL & 1))
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4v, v), rout, ob2, (i * 32 + r * 8) * a.out_stride * 2, 0);
+                        else if (v[0] == (_Float16)12345.f) dbg[0] = 1;
+                    });
+                });
+            }
             if (a.tiles_n > 1 && has_next) load_bias(tile + t_step);
         }
         if (has_next) {
@@ -343,32 +399,32 @@ inline bool geometry_ok(int H, int W, int TPX) {
     return bpx % W == 0 && H >= bpx / W;
 }
 
-template <int SEGL, int TPX, int DEPTH, int RELU, int ABL = 0, int DBG = 0>
+template <int SEGL, int TPX, int DEPTH, int RELU, int VAR = 0, int ABL = 0, int DBG = 0>
 inline int launch_r(pe::ConvWdArgs a, hipStream_t st, int workgroups, unsigned long long* dbg) {
     using G_ = Geo<SEGL, TPX>;
     a.seg = G_::SEG; a.nseg = G_::NSEG;
     a.tiles_m = pe::ceil_div(a.M, G_::BPX);
     a.tiles_n = a.Cout / (WN * 64);
-    const size_t lds = (size_t)3 * G_::SLAB;
-    PE_ENSURE_LDS((conv3x3_wd9_kernel<SEGL, TPX, DEPTH, RELU, ABL, DBG>), lds, "conv3x3_wd9");
+    const size_t lds = (size_t)3 * G_::SLAB + 16384;
+    PE_ENSURE_LDS((conv3x3_wd9_kernel<SEGL, TPX, DEPTH, RELU, VAR, ABL, DBG>), lds, "conv3x3_wd9");
     const int ntile = a.tiles_m * a.tiles_n;
-    hipLaunchKernelGGL((conv3x3_wd9_kernel<SEGL, TPX, DEPTH, RELU, ABL, DBG>), dim3(ntile < workgroups ? ntile : workgroups), dim3(THREADS), lds, st, a, dbg);
+    hipLaunchKernelGGL((conv3x3_wd9_kernel<SEGL, TPX, DEPTH, RELU, VAR, ABL, DBG>), dim3(ntile < workgroups ? ntile : workgroups), dim3(THREADS), lds, st, a, dbg);
     return PE_OK;
 }
 
-template <int SEGL, int TPX, int DEPTH, int ABL = 0, int DBG = 0>
+template <int SEGL, int TPX, int DEPTH, int VAR = 0, int ABL = 0, int DBG = 0>
 inline int launch_t(pe::ConvWdArgs a, hipStream_t st, int workgroups, unsigned long long* dbg) {
-    return a.relu ? launch_r<SEGL, TPX, DEPTH, 1, ABL, DBG>(a, st, workgroups, dbg) : launch_r<SEGL, TPX, DEPTH, 0, ABL, DBG>(a, st, workgroups, dbg);
+    return a.relu ? launch_r<SEGL, TPX, DEPTH, 1, VAR, ABL, DBG>(a, st, workgroups, dbg) : launch_r<SEGL, TPX, DEPTH, 0, VAR, ABL, DBG>(a, st, workgroups, dbg);
 }
 
-template <int TPX, int DEPTH, int ABL = 0, int DBG = 0>
+template <int TPX, int DEPTH, int VAR = 0, int ABL = 0, int DBG = 0>
 inline int launch(pe::ConvWdArgs a, hipStream_t st, int workgroups = 256, unsigned long long* dbg = nullptr) {
     if (!geometry_ok(a.H, a.W, TPX)) return PE_ERR_UNSUPPORTED;
     switch (a.W) {
-        case 256: if constexpr (TPX == 8) return launch_t<8, TPX, DEPTH, ABL, DBG>(a, st, workgroups, dbg); else return PE_ERR_UNSUPPORTED;
-        case 128: if constexpr (TPX % 4 == 0) return launch_t<7, TPX, DEPTH, ABL, DBG>(a, st, workgroups, dbg); else return PE_ERR_UNSUPPORTED;
-        case 64: if constexpr (TPX % 2 == 0) return launch_t<6, TPX, DEPTH, ABL, DBG>(a, st, workgroups, dbg); else return PE_ERR_UNSUPPORTED;
-        case 32: if constexpr (TPX <= 6) return launch_t<5, TPX, DEPTH, ABL, DBG>(a, st, workgroups, dbg); else return PE_ERR_UNSUPPORTED;
+        case 256: if constexpr (TPX == 8) return launch_t<8, TPX, DEPTH, VAR, ABL, DBG>(a, st, workgroups, dbg); else return PE_ERR_UNSUPPORTED;
+        case 128: if constexpr (TPX % 4 == 0) return launch_t<7, TPX, DEPTH, VAR, ABL, DBG>(a, st, workgroups, dbg); else return PE_ERR_UNSUPPORTED;
+        case 64: if constexpr (TPX % 2 == 0) return launch_t<6, TPX, DEPTH, VAR, ABL, DBG>(a, st, workgroups, dbg); else return PE_ERR_UNSUPPORTED;
+        case 32: if constexpr (TPX <= 6) return launch_t<5, TPX, DEPTH, VAR, ABL, DBG>(a, st, workgroups, dbg); else return PE_ERR_UNSUPPORTED;
     }
     return PE_ERR_UNSUPPORTED;
 }

@@ -10,6 +10,11 @@ extern "C" {
  *                                16: 256x256 kernel for every eligible launch
  *   reuse3x3 (default 1): 1 = kw-reuse 3x3 kernel, 0 = generic per-tap 3x3 kernel */
 int pe_test_set_conv_policy(int tile_bits, int reuse3x3);
+/* Which generation of the weights-direct 3x3 kernels takes a launch (both produce the same bits):
+ *   0 = conv_wd.h only, 1 = conv_wd9.h for launches of >= 128 tiles of 256 pixels (default), 2 = conv_wd9.h whenever the geometry allows */
+int pe_test_set_wd9_mode(int mode);
+/* 1 when a 3x3 launch of this shape is taken by the conv_wd9.h kernel under the current mode (bench.py labels its kernel table with it) */
+int pe_test_wd9_takes(int N, int H, int W, int Cin, int Cout);
 #ifdef __cplusplus
 }
 #endif

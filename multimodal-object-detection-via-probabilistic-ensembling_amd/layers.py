@@ -242,7 +242,9 @@ def conv3x3_wd(x, packed, bias, cout, *, relu=False, out=None, out_stride=0):
     _lib.check(st, "pe_conv3x3_wd_f16")
     if PROFILE is not None:
         M = N * H * W
-        PROFILE.append({"variant": "conv3x3_wd_kernel<1, 4, 4, 4, 0, 0>", "shape": f"N{N} {H}x{W} Cin{Cin} Cout{cout} k3 s1 res0 f320",
+        wd9 = _lib.test_hooks().pe_test_wd9_takes(N, H, W, Cin, cout)      # which kernel generation took the launch (same bits either way)
+        PROFILE.append({"variant": "conv3x3_wd9_kernel<8, 4, 5, 0>" if wd9 else "conv3x3_wd_kernel<1, 4, 4, 4, 0, 0>",
+                        "shape": f"N{N} {H}x{W} Cin{Cin} Cout{cout} k3 s1 res0 f320",
                         "flops": 2.0 * M * cout * 9 * Cin, "bytes": float(M * Cin * 2 + cout * 9 * Cin * 2 + M * cout * 2),
                         "replay": (lambda: conv3x3_wd(x, packed, bias, cout, relu=relu, out=out, out_stride=out_stride))})
     return out

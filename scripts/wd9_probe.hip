@@ -110,35 +110,54 @@ int main(int argc, char** argv) {
         a.wpk = dwp;
         g_ref.clear();
         run_variant("shipped wd<1,4,tpx4,d4>", [](pe::ConvWdArgs x) { return wd::launch_conv3x3_wd<1, 4, 4, 4>(x, 0); }, a, hin, hw, hb, hout, reps, true, true);
-        run_variant("wd9 tpx8 d4", [](pe::ConvWdArgs x) { return wd9::launch<8, 4>(x, 0); }, a, hin, hw, hb, hout, reps, false, true);
-        run_variant("wd9 tpx8 d6", [](pe::ConvWdArgs x) { return wd9::launch<8, 6>(x, 0); }, a, hin, hw, hb, hout, reps, false, true);
-        run_variant("  wd9 d4 abl: no stores", [](pe::ConvWdArgs x) { return wd9::launch<8, 4, 1>(x, 0); }, a, hin, hw, hb, hout, reps, false, false);
-        run_variant("  wd9 d4 abl: no slab DMA", [](pe::ConvWdArgs x) { return wd9::launch<8, 4, 2>(x, 0); }, a, hin, hw, hb, hout, reps, false, false);
-        run_variant("  wd9 d4 abl: no weight loads", [](pe::ConvWdArgs x) { return wd9::launch<8, 4, 4>(x, 0); }, a, hin, hw, hb, hout, reps, false, false);
-        run_variant("  wd9 d4 abl: none of them", [](pe::ConvWdArgs x) { return wd9::launch<8, 4, 7>(x, 0); }, a, hin, hw, hb, hout, reps, false, false);
-        if (s.W <= 64) {
-            run_variant("wd9 tpx6 d4", [](pe::ConvWdArgs x) { return wd9::launch<6, 4>(x, 0); }, a, hin, hw, hb, hout, reps, false, true);
-            run_variant("wd9 tpx4 d4 (1 wave/SIMD)", [](pe::ConvWdArgs x) { return wd9::launch<4, 4>(x, 0); }, a, hin, hw, hb, hout, reps, false, true);
-        }
-        if (si >= 2 && si <= 4) {   // timeline of three workgroups (cycles, s_memtime)
+        // timeline summary of a DBG build: average cycles per workgroup / per tile loop / per tile epilogue and the implied shader clock
+        auto timeline = [&](const char* name, auto launch_dbg) {
             hipMemset(dbg, 0, 256 * 128 * 8);
-            wd9::launch<8, 4, 0, 1>(a, 0, 256, dbg);
+            if (launch_dbg(a, dbg) != 0) return;
             hipDeviceSynchronize();
+            hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+            hipEventRecord(e0); launch_dbg(a, dbg); hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
             std::vector<unsigned long long> h(256 * 128);
             hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost);
-            unsigned long long t0 = ~0ull;
-            for (int b = 0; b < 256; ++b) if (h[b * 128] && h[b * 128] < t0) t0 = h[b * 128];
-            for (int b : {0, 1, 100}) {
-                printf("  timeline wg %d: start %llu |", b, h[b * 128] - t0);
-                for (int j = 0; j < 6 && h[b * 128 + 1 + j * 3]; ++j)
-                    printf(" tile%d loop %llu epi %llu gap %llu |", j, h[b * 128 + 2 + j * 3] - h[b * 128 + 1 + j * 3], h[b * 128 + 3 + j * 3] - h[b * 128 + 2 + j * 3],
-                           j ? h[b * 128 + 1 + j * 3] - h[b * 128 + 3 + (j - 1) * 3] : h[b * 128 + 1] - h[b * 128]);
-                printf("\n");
+            double tot = 0, loop = 0, epi = 0, epimax = 0, first = 0; int nw = 0, nt = 0;
+            for (int b = 0; b < 256; ++b) {
+                if (!h[b * 128]) continue;
+                int last = -1;
+                for (int j = 0; j < 40 && h[b * 128 + 1 + j * 3]; ++j) {
+                    const double l = (double)(h[b * 128 + 2 + j * 3] - h[b * 128 + 1 + j * 3]), e = (double)(h[b * 128 + 3 + j * 3] - h[b * 128 + 2 + j * 3]);
+                    loop += l; epi += e; epimax = e > epimax ? e : epimax; ++nt; last = j;
+                }
+                if (last < 0) continue;
+                first += (double)(h[b * 128 + 1] - h[b * 128]);
+                tot += (double)(h[b * 128 + 3 + last * 3] - h[b * 128]); ++nw;
             }
-            // spread of tile-end times over the workgroups (do they finish tiles in lockstep?)
-            unsigned long long lo = ~0ull, hi = 0;
-            for (int b = 0; b < 256; ++b) { const unsigned long long e = h[b * 128 + 2]; if (e) { lo = e < lo ? e : lo; hi = e > hi ? e : hi; } }
-            printf("  first-tile loop end: min %llu max %llu after the earliest start\n", lo - t0, hi - t0);
+            if (!nw) return;
+            printf("    [%s] wg cycles %.0f = %.3f GHz x %.4f ms | prologue %.0f | per tile: loop %.0f (ideal %d) epilogue %.0f (max %.0f) | tiles/wg %.1f\n", name, tot / nw,
+                   tot / nw / (ms * 1e6), ms, first / nw, loop / nt, (3 * s.Cin / 64) * 12 * 16 * 32, epi / nt, epimax, (double)nt / nw);
+            fflush(stdout);
+        };
+#define WD9_VARIANT(label, TPXv, Dv, VARv, chk)                                                                                              \
+        run_variant(label, [](pe::ConvWdArgs x) { return wd9::launch<TPXv, Dv, VARv>(x, 0); }, a, hin, hw, hb, hout, reps, false, chk);        \
+        timeline(label, [](pe::ConvWdArgs x, unsigned long long* d) { return wd9::launch<TPXv, Dv, VARv, 0, 1>(x, 0, 256, d); });
+#define WD9_ABL(label, TPXv, Dv, VARv, ABLv)                                                                                                 \
+        run_variant(label, [](pe::ConvWdArgs x) { return wd9::launch<TPXv, Dv, VARv, ABLv>(x, 0); }, a, hin, hw, hb, hout, reps, false, false); \
+        timeline(label, [](pe::ConvWdArgs x, unsigned long long* d) { return wd9::launch<TPXv, Dv, VARv, ABLv, 1>(x, 0, 256, d); });
+        WD9_VARIANT("wd9 tpx8 d4 dma-early", 8, 4, 0, true)
+        WD9_VARIANT("wd9 tpx8 d4 dma-late", 8, 4, 1, true)
+        WD9_VARIANT("wd9 tpx8 d4 reg-staged", 8, 4, 2, true)
+        WD9_VARIANT("wd9 tpx8 d4 dma-late + line stores", 8, 4, 5, true)
+        WD9_VARIANT("wd9 tpx8 d4 reg-staged + line stores", 8, 4, 6, true)
+        WD9_VARIANT("wd9 tpx8 d6 reg-staged + line stores", 8, 6, 6, true)
+        WD9_ABL("  abl (dma-late+lines): no stores", 8, 4, 5, 1)
+        WD9_ABL("  abl (dma-late+lines): no slab", 8, 4, 5, 2)
+        WD9_ABL("  abl (dma-late+lines): no weights", 8, 4, 5, 4)
+        WD9_ABL("  abl (dma-late+lines): none", 8, 4, 5, 7)
+        WD9_ABL("  abl (reg-staged+lines): no stores", 8, 4, 6, 1)
+        WD9_ABL("  abl (reg-staged+lines): no slab", 8, 4, 6, 2)
+        if (s.W <= 64) {
+            WD9_VARIANT("wd9 tpx6 d4 dma-late + line stores", 6, 4, 5, true)
+            WD9_VARIANT("wd9 tpx4 d4 dma-late + line stores", 4, 4, 5, true)
         }
         hipFree(din); hipFree(dw); hipFree(dwp); hipFree(dout); hipFree(db);
     }

@@ -166,6 +166,51 @@ def test_conv3x3_weights_direct_kernel(L, case):
     torch.testing.assert_close(outs[0].permute(0, 3, 1, 2).float(), ref, rtol=4e-3, atol=4e-3)
 
 
+@pytest.mark.parametrize("case", [
+    # N, H, W, Cin, Cout, relu, out window (offset, stride)
+    (3, 50, 64, 256, 256, True, None),          # res4 / p4 geometry: four image rows per tile, tiles straddle images, ragged last tile
+    (2, 20, 256, 64, 256, False, None),         # p2 geometry: one row per tile, three K groups only (the slab ring wraps inside a tile)
+    (2, 13, 128, 256, 256, False, (256, 512)),  # p3 geometry, odd row count (last tile has one row), channel-window output
+    (1, 9, 64, 128, 512, True, None),           # two channel tiles: the bias / weight stream switch between a workgroup's tiles
+    (40, 7, 64, 64, 256, True, None),           # more tiles than one round of workgroups would hold in the 8 per-XCD runs, H < 8
+])
+def test_conv3x3_wd9_is_bit_identical_to_conv_wd(L, case):
+    """csrc/conv_wd9.h (persistent workgroups, one wave per SIMD, accumulators in a[0:255] from inline-asm MFMAs, the slab by
+    LDS-DMA with an XOR swizzle, whole-line stores) against csrc/conv_wd.h ON THE SAME CALL: bit for bit, twice (race screen for
+    the counted vmcnt / barrier protocol of the DMA ring), and against torch fp32."""
+    from proben_amd import _lib
+    N, H, W, Cin, Cout, relu, window = case
+    g = torch.Generator(device="cpu").manual_seed(29)
+    x = torch.randn(N, Cin, H, W, generator=g).cuda().half()
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5).cuda().half()
+    b = torch.randn(Cout, generator=g).cuda()
+    ref = torch.nn.functional.conv2d(x.float(), w.float(), b, stride=1, padding=1)
+    if relu:
+        ref = ref.relu()
+    packed = L.conv_wd_pack(w.permute(0, 2, 3, 1).contiguous())
+    hooks = _lib.test_hooks()
+
+    def run():
+        if window is None:
+            return L.conv3x3_wd(nhwc(x), packed, b, Cout, relu=relu).clone()
+        off, stride = window
+        full = torch.full((N, H, W, stride), 7.0, dtype=torch.float16, device="cuda")
+        L.conv3x3_wd(nhwc(x), packed, b, Cout, relu=relu, out=full.view(-1)[off:], out_stride=stride)
+        assert torch.all(full[..., :off] == 7.0)
+        return full[..., off:off + Cout].clone()
+    try:
+        hooks.pe_test_set_wd9_mode(0)
+        old = run()
+        hooks.pe_test_set_wd9_mode(2)
+        new1, new2 = run(), run()
+    finally:
+        hooks.pe_test_set_wd9_mode(1)
+    torch.cuda.synchronize()
+    assert torch.equal(new1, new2)
+    assert torch.equal(new1, old)
+    torch.testing.assert_close(new1.permute(0, 3, 1, 2).float(), ref, rtol=4e-3, atol=4e-3)
+
+
 @pytest.mark.parametrize("shape", [(2, 40, 64, 256), (1, 13, 128, 256), (3, 5, 32, 256), (2, 8, 256, 512)])
 def test_fused_rpn_head_matches_two_launch_path_and_torch(L, shape):
     """StandardRPNHead (proposal_generator/rpn.py:74-85) in one launch == 3x3 + ReLU then the 15-column 1x1 (the fp16
