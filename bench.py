@@ -66,6 +66,11 @@ def parse(argv=None):
     ap.add_argument("--no-tail-fusion", action="store_true", help="A/B: run conv2 and conv3 of the res4 bottlenecks as two launches")
     ap.add_argument("--no-res2-fusion", action="store_true", help="A/B: run res2 as separate conv launches instead of the fused 64-wide chain")
     ap.add_argument("--serial-detectors", action="store_true", help="run the detectors back to back on one stream")
+    ap.add_argument("--wd9-tail-wgs", type=int, default=0, help="A/B: workgroups of the persistent fused-tail kernel (0 = the library's default)")
+    ap.add_argument("--wd9-wgs", type=int, default=0, help="A/B: workgroups of the persistent pure 3x3 kernel (0 = the library's default)")
+    ap.add_argument("--wd9-mode", type=int, default=-1,
+                    help="A/B (csrc/test_hooks.h): 0 = two-wave weights-direct kernels only (csrc/conv_wd.h), 1 = persistent one-wave-per-SIMD "
+                         "kernel for the pure 3x3 launches, 4 = for the fused res4 tail, 5 = both; -1 = the library's default")
     ap.add_argument("--stagger", type=int, default=3,
                     help="N > 0 (default 3, two-detector configs): throughput mode of the pipeline - detector 2 trails detector 1 by its "
                          "res<N> stage and batches follow each other without a device-wide wait (all K timed steps still complete "
@@ -352,6 +357,12 @@ def main(argv=None):
     cfg = CONFIGS[args.config]
     depth = args.depth or cfg["depth"]
     B = args.batch or cfg["batch"]
+    if args.wd9_tail_wgs > 0 or args.wd9_wgs > 0:
+        from proben_amd import _lib
+        _lib.test_hooks().pe_test_set_wd9_wgs(args.wd9_wgs, args.wd9_tail_wgs)
+    if args.wd9_mode >= 0:
+        from proben_amd import _lib
+        _lib.test_hooks().pe_test_set_wd9_mode(args.wd9_mode)
     models, sds = build_models(cfg, depth, dev, use_wd=not args.no_wd, fuse_tails=not args.no_tail_fusion, fuse_res2=not args.no_res2_fusion)
     feeder = None
     if args.feed == "host":

@@ -6,24 +6,53 @@
 // -mllvm -amdgpu-spill-vgpr-to-agpr=0 (the AGPRs a[0:255] belong to the asm statements: the compiler must never park a VGPR there);
 // tests/test_build_audit.py checks the emitted code for scratch use and for accumulator-file instructions outside the asm blocks.
 #include "conv_wd9.h"
+#include "conv_wd9_tail.h"
 
 namespace pe {
-// 0 = never, 1 = when the launch has at least kWd9MinTiles tiles (default), 2 = whenever the geometry allows (tests)
-int g_wd9_mode = 1;
+// bit 0: the pure 3x3 kernel takes launches of at least kWd9MinTiles tiles; bit 1: ... whenever the geometry allows (tests);
+// bit 2: the fused bottleneck tail of image width 64 runs on conv_wd9_tail.h
+int g_wd9_mode = 1 | 4;
+// workgroups of the persistent kernels (pure 3x3, fused tail): one per CU when a launch has the chip to itself; the two-detector
+// pipeline runs the detectors on two streams, and a kernel that occupies every CU for its whole duration shuts the other stream out
+int g_wd9_wgs = 256, g_wd9_tail_wgs = 256;
 constexpr int kWd9MinTiles = 128;
 
 static bool wd9_takes(int H, int W, long long M, int Cout) {
-    if (g_wd9_mode == 0 || !wd9::geometry_ok(H, W, 8) || W < 64) return false;
+    if (!(g_wd9_mode & 3) || !wd9::geometry_ok(H, W, 8) || W < 64) return false;
     const long long tiles = (long long)ceil_div(M, 256) * (Cout / 256);
-    return g_wd9_mode == 2 || tiles >= kWd9MinTiles;
+    return (g_wd9_mode & 2) || tiles >= kWd9MinTiles;
 }
 
 // pure 3x3 (+ bias, optional ReLU): PE_OK when launched, PE_ERR_UNSUPPORTED when the caller should use conv_wd.h's kernel
 int wd9_conv3x3(ConvWdArgs a, hipStream_t st) {
     if (!wd9_takes(a.H, a.W, a.M, a.Cout)) return PE_ERR_UNSUPPORTED;
-    return wd9::launch<8, 4, 5>(a, st);
+    return wd9::launch<8, 4, 5>(a, st, g_wd9_wgs);
+}
+
+// fused bottleneck tail: the kernel is chosen by GEOMETRY only (image width 64 = res4 of an 800 x 1024 padded input) - the two
+// generations add the shortcut at different points of the sum, so a batch-size-dependent choice would show in the results
+static bool wd9_tail_takes(int H, int W, int Cin, int tail_cout) { return (g_wd9_mode & 4) && wd9t::geometry_ok(H, W, Cin, tail_cout); }
+
+int wd9_bottleneck_tail(ConvWdArgs a, hipStream_t st) {
+    if (!wd9_tail_takes(a.H, a.W, a.Cin, a.tail_cout)) return PE_ERR_UNSUPPORTED;
+    return wd9t::launch<4, 4>(a, st, g_wd9_tail_wgs);
 }
 }  // namespace pe
+
+extern "C" int pe_conv_wd_set_concurrent_streams(int32_t streams) {
+    PE_CHECK_ARG(streams >= 1 && streams <= 8, "pe_conv_wd_set_concurrent_streams: streams must be in 1 .. 8 (got %d)", streams);
+    pe::g_wd9_tail_wgs = 256 / streams / 8 * 8;
+    return PE_OK;
+}
+
+extern "C" int pe_test_set_wd9_wgs(int pure, int tail) {
+    auto clamp = [](int n) { return n < 8 ? 8 : (n > 256 ? 256 : n / 8 * 8); };
+    if (pure > 0) pe::g_wd9_wgs = clamp(pure);
+    if (tail > 0) pe::g_wd9_tail_wgs = clamp(tail);
+    return PE_OK;
+}
+
+extern "C" int pe_test_wd9_tail_takes(int H, int W, int Cin, int tail_cout) { return pe::wd9_tail_takes(H, W, Cin, tail_cout) ? 1 : 0; }
 
 // measurement hook (csrc/test_hooks.h): 1 when a 3x3 launch of this shape runs on the conv_wd9.h kernel
 extern "C" int pe_test_wd9_takes(int N, int H, int W, int Cin, int Cout) {

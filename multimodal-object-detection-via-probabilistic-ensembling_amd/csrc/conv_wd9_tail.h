@@ -1,0 +1,391 @@
+// Fused bottleneck tail on the conv_wd9.h structure (round 4): conv2 3x3 + FrozenBN + ReLU -> conv3 1x1 + FrozenBN + shortcut + ReLU
+// of a BottleneckBlock (backbone/resnet.py:205-221) in ONE persistent launch, one wave per SIMD.
+//
+// Replaces conv3x3_wd_kernel<1,4,4,4,0,2> (conv_wd.h) for the geometry that carries 70 % of ResNet-101's 3x3 flops: res4, image
+// width 64 (an 800 x 1024 padded input).  The kernel is chosen by GEOMETRY only (never by batch size), so a frame's result does not
+// depend on the batch it travels in.
+//
+//   * tile = 3 image rows = 192 pixels (NPB = 6 pixel blocks) x all channels; a workgroup owns a contiguous run of image rows
+//     (6 or 7 rows of the 1600 at batch 32) and walks it in 3-row tiles plus 1-row tiles (NPB = 2) for the remainder;
+//   * phase A = conv_wd9.h's K-loop (accumulators a[0:191] from inline-asm MFMAs, slab by LDS-DMA, weight records L2 -> VGPR);
+//   * t = relu(conv2 + bias) goes to LDS as fp16 (192 x 512 B, chunk c of pixel p in slot c ^ (p & 15));
+//   * phase B: every wave computes 256 of the tail_cout outputs in chunks of 64 (t fragments from LDS, conv3 records L2 -> VGPR).
+//     The SHORTCUT enters through the matrix pipe: its 16-byte pieces are loaded straight into MFMA B-fragment layout (lane =
+//     pixel, 8 channels) and multiplied by two constant 0/1 fragments, so the fp32 add costs no VALU and no accumulator read; the
+//     loads of a whole chunk (96 VGPRs) are requested a chunk ahead of their use - a lane's four pieces of a line together, which
+//     the 241-register two-wave kernel could not afford (its quarter-order reads re-fetched 1.3x);
+//   * the output leaves as whole 128-byte lines through a wave-private LDS patch;
+//   * LDS map (160 KiB): T = [0, 96 Ki) holds t during phase B; the slab ring of phase A is {S0 = [96 Ki, 128 Ki), S1 = [128 Ki,
+//     160 Ki), T0 = [0, 32 Ki)} with slab g in slot g % 3.  The next tile's slab 0 is DMAed into S0 during this tile's group
+//     G - 2, so it is in place before phase B starts; S1 carries the store patches during phase B and receives the tile's slab 1
+//     one group ahead, during group 0 (a counted wait in front of that group's barrier), T0 its slab 2.
+//   Summation order of EVERY output: shortcut (exact) + K-steps 0 .. 15 in order, + bias, ReLU - independent of the pixel's place in a tile.
+#pragma once
+#include "conv_wd9.h"
+
+namespace wd9t {
+using wd::float16v;
+using wd::half8;
+using wd9::acc_read8;
+using wd9::dma16;
+using wd9::ic;
+using wd9::int4v;
+using wd9::make_rsrc;
+using wd9::mfma_acc;
+using wd9::mfma_zero;
+using wd9::static_for;
+using wd9::uint4v;
+
+constexpr int THREADS = 256, WN = 4;
+constexpr int SEGL = 6, SEG = 64, SEGP = 80, NSEGM = 3, E = 256, SLAB = E * 128, NPIECE = E / 8, PPW = NPIECE / 4;   // 3 rows x 80 entries, padded to 256
+constexpr int T_BYTES = 192 * 512, S0_OFF = T_BYTES, S1_OFF = T_BYTES + SLAB, LDS_BYTES = T_BYTES + 2 * SLAB;
+// Accumulator block (blk, i) of a tile with NPB pixel blocks = a[ACC0 + (blk * NPB + i) * 16 ...].  The asm statements own a[64:255];
+// a[0:63] are LEFT TO THE COMPILER, which parks workgroup-lifetime values (DMA descriptors, bias, addresses) there across the tile
+// loop when the 256 architectural registers run short (tests/test_build_audit.py checks that it stays below a64).
+constexpr int ACC0 = 64;
+static_assert(LDS_BYTES == 160 * 1024, "the layout uses the whole LDS of a CU");
+
+// DEPTH: K-steps of weight-record prefetch in phase A (conv2); DB: the same in phase B (conv3).  The counter that retires vector-memory
+//   operations is in-order: a record requested behind a slab DMA or a shortcut piece (both HBM) is not usable before that older
+//   request has returned, so the prefetch distance has to cover an HBM round trip, not an L2 one.
+// ABL (measurement builds, results wrong): 1 = no output stores, 2 = no shortcut loads, 8 = skip phase B
+// DBG: wave 0 of every workgroup stamps s_memtime at kernel start and per tile: start, end of phase A, end of phase B
+template <int DEPTH = 4, int DB = 2, int ABL = 0, int DBG = 0>
+__global__ __launch_bounds__(THREADS, 1) void conv3x3_wd9_tail_kernel(pe::ConvWdArgs a, unsigned long long* dbg) {
+    static_assert(12 % DEPTH == 0 && 16 % DB == 0, "prefetch depths divide the K-steps of a group / a chunk");
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    typedef __attribute__((address_space(3))) unsigned char lds_byte;
+    const unsigned smem_base = (unsigned)(unsigned long long)(lds_byte*)smem;
+    asm volatile("" ::: "a255");            // makes the kernel descriptor allocate the whole accumulation file
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int px = lane & 31, hq = lane >> 5;
+    const int G = 3 * (a.Cin / 64);          // K groups of phase A: slab g lives in ring slot g % 3, every tile starts at slot 0
+    const int R = a.M >> SEGL;               // image rows in the batch
+    const int NCH = a.tail_cout / 256;       // 64-output chunks per wave
+
+    // ---- this workgroup's image rows: contiguous, neighbours (which share halo rows) on the same XCD ----
+    const int nwg = gridDim.x;
+    const int lid = (nwg % 8 == 0) ? (blockIdx.x % 8) * (nwg / 8) + blockIdx.x / 8 : blockIdx.x;
+    const int r_begin = (int)((long long)lid * R / nwg), r_end = (int)((long long)(lid + 1) * R / nwg);
+    if (r_begin >= r_end) return;
+
+    auto slot_off = [&](int s) { return s == 0 ? S0_OFF : (s == 1 ? S1_OFF : 0); };
+
+    // ---- DMA pieces of this lane (conv_wd9.h): piece k = slab piece q = 4 k + wn, entry e = 8 q + (lane >> 3) ----
+    int rel[PPW], sg[PPW];
+#pragma unroll
+    for (int k = 0; k < PPW; ++k) {
+        const int q = k * 4 + wn;
+        const int e = q * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((e >> 1) & 7);
+        const int s = e / SEGP, jj = e - s * SEGP - 1;
+        sg[k] = s;
+        rel[k] = (s < NSEGM && (unsigned)jj < (unsigned)SEG) ? ((s * SEG + jj) * a.Cin + c * 8) * 2 : -1;
+    }
+    const int4v rin = make_rsrc(a.in, (unsigned)a.M * (unsigned)a.Cin * 2u);
+    int voffc[PPW], badk[PPW];
+    auto describe = [&](int row0, int nrows) {     // the tile whose slabs are being loaded: first row (global index), valid rows (0: none)
+        const int h0 = row0 % a.H;
+#pragma unroll
+        for (int k = 0; k < PPW; ++k) {
+            int hs = h0 + sg[k];
+            hs = hs >= a.H ? hs - a.H : hs;
+            const bool never = (rel[k] < 0) | (sg[k] >= nrows);
+            voffc[k] = rel[k] + (row0 << SEGL) * a.Cin * 2;
+            badk[k] = (never ? 4 : 0) | (hs == 0 ? 1 : 0) | (hs == a.H - 1 ? 2 : 0);
+        }
+    };
+    auto dma_piece = [&](int k, int slot, int shift, int khbits) {
+        const unsigned vo = (badk[k] & khbits) ? 0x80000000u : (unsigned)(voffc[k] + shift);
+        dma16(vo, smem_base + slot_off(slot) + (k * 4 + wn) * 1024, rin);
+    };
+    auto group_shift = [&](int g) { const int cc = g / 3, kh = g - cc * 3; return ((kh - 1) * SEG * a.Cin + cc * 64) * 2; };
+    auto group_khbits = [&](int g) { const int kh = g % 3; return 4 | (kh == 0 ? 1 : 0) | (kh == 2 ? 2 : 0); };
+
+    // ---- fragment read addresses of phase A: tap kw (K-step ks = XOR with ks << 5), pixel block i adds an immediate ----
+    int fa0[3];
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+        const int e = px + kw;
+        fa0[kw] = e * 128 + ((hq ^ ((e >> 1) & 7)) * 16);
+    }
+    auto blk_off = [](int i) constexpr { return ((i >> 1) * SEGP + (i & 1) * 32) * 128; };
+    // phase B: t fragment of pixel block i, K-step ks: (i * 32 + px) * 512 + (((ks * 2 + hq) ^ (px & 15)) << 4) = tb0 ^ (ks << 5) + i * 16384
+    const int tb0 = px * 512 + ((hq ^ (px & 15)) << 4);
+
+    // ---- weights: conv2 records (pe_conv_wd_pack_weights, one channel tile) and conv3 records (pe_conv_wd_pack_tail) ----
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.wpk), 0, 256 * a.Cin * 18, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.tail_w), 0, a.tail_cout * 256 * 2, 0x00020000);
+    const int w_base = wn * 2048, t_base = wn * NCH * 16 * 2048;
+    half8 wf[DEPTH > DB ? DEPTH : DB][2];
+    auto w_load1 = [&](int slot, int blk, int so) {
+        wf[slot][blk] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16 + blk * 1024, so, 0));
+    };
+    auto t_load1 = [&](int slot, int blk, int so) {
+        wf[slot][blk] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rt, lane * 16 + blk * 1024, so, 0));
+    };
+
+    // ---- the shortcut as MFMA B fragments, and the two 0/1 A fragments that route its channels to accumulator rows:
+    // accumulator row rho of block blk is channel ((rho >> 2) & 1) * 32 + blk * 16 + (rho >> 3) * 4 + (rho & 3) of the chunk
+    // (wd::cout_perm), i.e. K slice 2 j + blk with j = (rho >> 2) & 1, position (rho >> 3) * 4 + (rho & 3) inside the slice ----
+    half8 idf[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int pos = (px >> 3) * 4 + (px & 3);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) idf[j][e] = (((px >> 2) & 1) == j && (pos >> 3) == hq && (pos & 7) == e) ? (_Float16)1.f : (_Float16)0.f;
+    }
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.tail_res ? a.tail_res : a.in), 0,
+                                                                        (a.tail_res && !(ABL & 2)) ? a.M * a.tail_cout * 2 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(a.tail_out, 0, a.M * a.tail_cout * 2, 0x00020000);
+
+    unsigned long long* dbgp = nullptr;
+    if (DBG) {
+        dbgp = dbg + (size_t)blockIdx.x * 128;
+        if (tid == 0) dbgp[0] = __builtin_readcyclecounter();
+    }
+
+    // ---- prologue: slab 0 of the first tile ----
+    {
+        const int nr = r_end - r_begin >= 3 ? 3 : 1;
+        describe(r_begin, nr);
+#pragma unroll
+        for (int k = 0; k < PPW; ++k) dma_piece(k, 0, group_shift(0), group_khbits(0));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    int tcount = 0;
+    // one tile of NPB pixel blocks (6 = three image rows, 2 = one row) starting at image row `row0`; `nrow_next` = rows of the tile
+    // after it (0: none) - its slab 0 is loaded during group G - 2
+    auto tile = [&](auto npb_, int row0, int next_row0, int nrow_next) {
+        constexpr int NPB = decltype(npb_)::value;
+        constexpr int NB = NPB / 2;                  // shortcut batches (2 pixel blocks = 32 VGPRs) per chunk, each in its own registers
+        const int m0 = row0 << SEGL;
+        if (DBG && tid == 0 && tcount < 40) dbgp[1 + tcount * 3] = __builtin_readcyclecounter();
+
+        // =========================== phase A: t = relu(conv3x3(in) + bias) ===========================
+        half8 pf[2][NPB];
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) { w_load1(d, 0, w_base + d * (WN * 2048)); w_load1(d, 1, w_base + d * (WN * 2048)); }
+#pragma unroll
+        for (int i = 0; i < NPB; ++i) pf[0][i] = *reinterpret_cast<const half8*>(smem + S0_OFF + fa0[0] + blk_off(i));
+        // One K group (12 K-steps over one slab).  The three forms - the tile's first group, a middle group, the last group - are
+        // separate instantiations: a branch inside a K-step would make the number of loads in flight depend on the path taken, and
+        // the compiler then drains the whole weight ring (s_waitcnt vmcnt(0)) where the paths join.
+        //   first:  C = 0 in K-step 0; this tile's slab 1 one group ahead (slot 1 = S1, free since the previous tile's phase B) AND
+        //           slab 2 two groups ahead;
+        //   middle: slab g + 2 two groups ahead (during group G - 2: the NEXT tile's slab 0, into S0);
+        //   last:   no DMA (S1 is phase B's patch area), no fragment prefetch in K-step 11, no weight records beyond the tile.
+        int cur = 0;
+        auto group = [&](auto first_, auto last_, int g) {
+            constexpr bool GF = decltype(first_)::value, GL = decltype(last_)::value;
+            const int nxt = cur == 2 ? 0 : cur + 1;
+            const int nn = nxt == 2 ? 0 : nxt + 1;
+            const int gl = g + 2 >= G ? 0 : g + 2;
+            const int l_shift = group_shift(gl), l_kh = group_khbits(gl);
+            const int c_shift = group_shift(1), c_kh = group_khbits(1);
+            const int sb = slot_off(cur), sn = slot_off(nxt);
+            const int wo_g = w_base + g * 12 * (WN * 2048);
+            auto kstep = [&](auto tc) {
+                constexpr int t = decltype(tc)::value;
+                constexpr bool FIRST = GF && t == 0;
+                constexpr int slot = t % DEPTH;
+                constexpr int kw1 = ((t + 1) % 12) / 4, ks1 = ((t + 1) % 12) % 4;
+                constexpr bool PREF = t + 1 < 12 || !GL;             // the next step's fragments
+                constexpr bool WLOAD = t + DEPTH < 12 || !GL;        // the records of K-step t + DEPTH
+                const unsigned char* src = smem + (t + 1 < 12 ? sb : sn) + (fa0[kw1] ^ (ks1 << 5));
+                const int wso = wo_g + (t + DEPTH) * (WN * 2048);
+                static_for<NPB>([&](auto i_) {
+                    constexpr int i = decltype(i_)::value;
+                    if constexpr (FIRST) mfma_zero<ACC0 + i * 16>(wf[slot][0], pf[t & 1][i]);
+                    else mfma_acc<ACC0 + i * 16>(wf[slot][0], pf[t & 1][i]);
+                    if constexpr (PREF) pf[(t + 1) & 1][i] = *reinterpret_cast<const half8*>(src + blk_off(i));
+                });
+                static_for<NPB>([&](auto i_) {
+                    constexpr int i = decltype(i_)::value;
+                    if constexpr (FIRST) mfma_zero<ACC0 + (NPB + i) * 16>(wf[slot][1], pf[t & 1][i]);
+                    else mfma_acc<ACC0 + (NPB + i) * 16>(wf[slot][1], pf[t & 1][i]);
+                    if constexpr (i == 0 && WLOAD) w_load1(slot, 0, wso);
+                    if constexpr (i == (NPB > 2 ? 2 : 0) && t < PPW && GF) dma_piece(t, 1, c_shift, c_kh);
+                    if constexpr (i == (NPB > 4 ? 4 : NPB - 1) && t < PPW && !GL) dma_piece(t, nn, l_shift, l_kh);
+                });
+                if constexpr (WLOAD) w_load1(slot, 1, wso);
+            };
+            static_for<11>(kstep);
+            // slab g + 1 must be in place before K-step 11 prefetches from it: issued during group g - 1 (>= 22 weight records
+            // since), except slab 1, issued during K-steps 0 .. 7 of the first group (the records of K-steps 8 .. 10 since)
+            if constexpr (GF) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if constexpr (GL) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");      // the last group requests 16 records before K-step 11
+            else asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
+            __syncthreads();
+            kstep(ic<11>{});
+            cur = nxt;
+        };
+        group(std::true_type{}, std::false_type{}, 0);
+        for (int g = 1; g < G - 1; ++g) {
+            if (g == G - 2) describe(next_row0, nrow_next);      // from here on the slab DMAs belong to the next tile
+            group(std::false_type{}, std::false_type{}, g);
+        }
+        group(std::false_type{}, std::true_type{}, G - 1);
+        // ---- shortcut pieces of the first chunk's first batches (their latency hides behind the t conversion below) ----
+        unsigned rbase[NPB];
+#pragma unroll
+        for (int i = 0; i < NPB; ++i) {
+            const int m = m0 + i * 32 + px;
+            rbase[i] = m < a.M ? (unsigned)(((size_t)m * a.tail_cout + wn * (NCH * 64) + hq * 8) * 2) : 0x80000000u;
+        }
+        half8 sc[NB][2][4];
+        auto sc_load = [&](int slotv, auto b_, int c, bool none) {   // batch b (pixel blocks 2 b, 2 b + 1) of chunk c: 8 loads; none: no such
+            constexpr int b = decltype(b_)::value;                   // chunk - out-of-range offsets, no traffic, no branch
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int k4 = 0; k4 < 4; ++k4)
+                    sc[slotv][u][k4] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rr, none ? 0x80000000u : rbase[2 * b + u],
+                                                                                                       c * 128 + k4 * 32, 0));
+        };
+        if (!(ABL & 8)) static_for<NB>([&](auto b_) { sc_load(decltype(b_)::value, b_, 0, false); });
+        // ---- t -> LDS (every wave has passed the last group's barrier: nobody reads a slab any more) ----
+        {
+            float16v b2[2];
+            const float* bp = a.bias + wn * 64 + hq * 32;
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const float4 v = *reinterpret_cast<const float4*>(bp + blk * 16 + r4 * 4);
+                    b2[blk][r4 * 4 + 0] = v.x; b2[blk][r4 * 4 + 1] = v.y; b2[blk][r4 * 4 + 2] = v.z; b2[blk][r4 * 4 + 3] = v.w;
+                }
+            asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7");
+            static_for<NPB * 4>([&](auto q_) {
+                constexpr int q = decltype(q_)::value, i = q >> 2, blk = (q >> 1) & 1, hh = q & 1;
+                float x[8];
+                acc_read8<ACC0 + (blk * NPB + i) * 16 + hh * 8>(x);
+                half8 v;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (_Float16)(x[e] + b2[blk][hh * 8 + e]);
+                v = __builtin_elementwise_maximum(v, (half8)(_Float16)0.f);
+                const int chunk = wn * 8 + hq * 4 + blk * 2 + hh;
+                *reinterpret_cast<half8*>(smem + (i * 32 + px) * 512 + ((chunk ^ (px & 15)) << 4)) = v;
+            });
+        }
+        __syncthreads();
+        if (DBG && tid == 0 && tcount < 40) dbgp[2 + tcount * 3] = __builtin_readcyclecounter();
+
+        // =========================== phase B: out = relu(conv1x1(t) + bias + shortcut) ===========================
+        if (!(ABL & 8)) {
+            unsigned char* patch = smem + S1_OFF + wn * 4096;
+            const int rrow = lane >> 3, rc = (lane & 7) ^ (rrow & 7);
+            const unsigned ob2 = (unsigned)(((m0 + rrow) * a.tail_cout + wn * (NCH * 64) + rc * 8) * 2);
+            auto tfrag = [&](int ks, auto i_) {       // t fragment of pixel block i, K-step ks
+                constexpr int i = decltype(i_)::value;
+                return *reinterpret_cast<const half8*>(smem + (tb0 ^ (ks << 5)) + i * 16384);
+            };
+            // One chunk of 64 outputs per wave.  EVERY accumulator is opened by its shortcut (the first MFMAs of the chunk): the place of
+            // the shortcut in an output's fp32 sum must not depend on where the pixel sits in its tile - tiles shift against the
+            // images with the batch composition, and a frame's result may not depend on the batch it travels in.
+            auto chunk = [&](int c) {
+                const int tb = t_base + c * 16 * 2048;
+#pragma unroll
+                for (int d = 0; d < DB; ++d) { t_load1(d, 0, tb + d * 2048); t_load1(d, 1, tb + d * 2048); }
+                static_for<NPB>([&](auto i_) { pf[0][decltype(i_)::value] = tfrag(0, i_); });
+                const bool more = c + 1 < NCH;
+                auto bstep = [&](auto sc_) {
+                    constexpr int s = decltype(sc_)::value;
+                    constexpr int slot = s % DB;
+                    if constexpr (s == 0) {
+                        static_for<NB>([&](auto b_) {
+                            constexpr int bat = decltype(b_)::value;
+                            static_for<2>([&](auto u_) {
+                                constexpr int u = decltype(u_)::value, i = 2 * bat + u;
+                                mfma_zero<ACC0 + i * 16>(idf[0], sc[bat][u][0]);            // exact: 1.0 x shortcut + 0
+                                mfma_zero<ACC0 + (NPB + i) * 16>(idf[0], sc[bat][u][1]);
+                                mfma_acc<ACC0 + i * 16>(idf[1], sc[bat][u][2]);
+                                mfma_acc<ACC0 + (NPB + i) * 16>(idf[1], sc[bat][u][3]);
+                            });
+                            sc_load(bat, b_, c + 1, !more);         // the registers are free: the next chunk's pieces, a whole chunk ahead
+                        });
+                    }
+                    const int tso = tb + (s + DB) * 2048;
+                    static_for<NPB>([&](auto i_) {
+                        constexpr int i = decltype(i_)::value;
+                        mfma_acc<ACC0 + i * 16>(wf[slot][0], pf[s & 1][i]);
+                        if constexpr (s + 1 < 16) pf[(s + 1) & 1][i] = tfrag(s + 1, i_);
+                    });
+                    static_for<NPB>([&](auto i_) {
+                        constexpr int i = decltype(i_)::value;
+                        mfma_acc<ACC0 + (NPB + i) * 16>(wf[slot][1], pf[s & 1][i]);
+                        if constexpr (i == 0 && s + DB < 16) t_load1(slot, 0, tso);
+                    });
+                    if constexpr (s + DB < 16) t_load1(slot, 1, tso);
+                };
+                static_for<16>(bstep);
+                // ---- chunk epilogue: + bias, ReLU, fp16, whole 128-byte lines through the wave's patch ----
+                {
+                    float16v b3[2];
+                    const float* bp = a.tail_b + wn * (NCH * 64) + c * 64 + hq * 32;
+#pragma unroll
+                    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                        for (int r4 = 0; r4 < 4; ++r4) {
+                            const float4 v = *reinterpret_cast<const float4*>(bp + blk * 16 + r4 * 4);
+                            b3[blk][r4 * 4 + 0] = v.x; b3[blk][r4 * 4 + 1] = v.y; b3[blk][r4 * 4 + 2] = v.z; b3[blk][r4 * 4 + 3] = v.w;
+                        }
+                    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7");
+                    static_for<NPB>([&](auto i_) {
+                        constexpr int i = decltype(i_)::value;
+                        static_for<4>([&](auto q_) {
+                            constexpr int q = decltype(q_)::value, blk = q >> 1, hh = q & 1;
+                            float x[8];
+                            acc_read8<ACC0 + (blk * NPB + i) * 16 + hh * 8>(x);
+                            half8 v;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] = (_Float16)(x[e] + b3[blk][hh * 8 + e]);
+                            v = __builtin_elementwise_maximum(v, (half8)(_Float16)0.f);
+                            *reinterpret_cast<half8*>(patch + px * 128 + (((hq * 4 + blk * 2 + hh) ^ (px & 7)) * 16)) = v;
+                        });
+                        static_for<4>([&](auto r_) {
+                            constexpr int r = decltype(r_)::value;
+                            const half8 v = *reinterpret_cast<const half8*>(patch + (r * 8) * 128 + lane * 16);
+                            if (!(ABL & 1))
+                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4v, v), rout, ob2, ((i * 32 + r * 8) * a.tail_cout + c * 64) * 2, 0);
+                            else if (v[0] == (_Float16)12345.f) dbg[0] = 1;
+                        });
+                    });
+                }
+            };
+            for (int c = 0; c < NCH; ++c) chunk(c);
+        }
+        __syncthreads();       // T, S1 and (after the DMA wait of group G - 1) S0 change hands
+        if (DBG && tid == 0 && tcount < 40) dbgp[3 + tcount * 3] = __builtin_readcyclecounter();
+        ++tcount;
+    };
+
+    for (int row = r_begin; row < r_end;) {
+        const int left = r_end - row;
+        const int nr = left >= 3 ? 3 : 1;
+        const int nleft = left - nr;
+        const int nnext = nleft >= 3 ? 3 : (nleft > 0 ? 1 : 0);
+        if (nr == 3) tile(ic<6>{}, row, row + nr, nnext);
+        else tile(ic<2>{}, row, row + nr, nnext);
+        row += nr;
+    }
+}
+
+inline bool geometry_ok(int H, int W, int Cin, int tail_cout) { return W == 64 && H >= 3 && Cin % 64 == 0 && Cin > 0 && tail_cout % 256 == 0; }
+
+template <int DEPTH = 4, int DB = 2, int ABL = 0, int DBG = 0>
+inline int launch(pe::ConvWdArgs a, hipStream_t st, int workgroups = 256, unsigned long long* dbg = nullptr) {
+    if (!geometry_ok(a.H, a.W, a.Cin, a.tail_cout)) return PE_ERR_UNSUPPORTED;
+    const int R = a.N * a.H;
+    int nwg = (R + 2) / 3;
+    if (nwg > workgroups) nwg = workgroups;
+    PE_ENSURE_LDS((conv3x3_wd9_tail_kernel<DEPTH, DB, ABL, DBG>), (size_t)LDS_BYTES, "conv3x3_wd9_tail");
+    hipLaunchKernelGGL((conv3x3_wd9_tail_kernel<DEPTH, DB, ABL, DBG>), dim3(nwg), dim3(THREADS), LDS_BYTES, st, a, dbg);
+    return PE_OK;
+}
+
+}  // namespace wd9t

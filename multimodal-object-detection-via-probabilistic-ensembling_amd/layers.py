@@ -214,6 +214,12 @@ def conv2d_nhwc(x, weight, bias, *, kernel, stride=1, relu=False, residual=None,
     return out
 
 
+def set_concurrent_streams(n):
+    """Tell the library how many detectors run concurrently on their own HIP streams (pipeline.py): its persistent kernels then
+    leave CUs to the other streams' launches.  Process-global; never changes results."""
+    _lib.check(_lib.lib().pe_conv_wd_set_concurrent_streams(int(n)), "pe_conv_wd_set_concurrent_streams")
+
+
 def conv_wd_supported(kernel, stride, H, W, Cin, Cout):
     """True when the weights-direct kernel (csrc/conv_wd.h) takes this geometry."""
     return bool(_lib.lib().pe_conv_wd_supported(int(kernel), int(stride), int(H), int(W), int(Cin), int(Cout)))
@@ -274,7 +280,9 @@ def bottleneck_tail_wd(x, packed3x3, bias3x3, packed_tail, tail_bias, residual, 
     _lib.check(st, "pe_bottleneck_tail_wd_f16")
     if PROFILE is not None:
         M = N * H * W
-        PROFILE.append({"variant": "conv3x3_wd_kernel<1, 4, 4, 4, 0, 2>", "shape": f"N{N} {H}x{W} Cin{Cin} Cout256->{tail_cout} k3+k1 s1 res{int(residual is not None)} f320",
+        wd9 = _lib.test_hooks().pe_test_wd9_tail_takes(H, W, Cin, tail_cout)
+        PROFILE.append({"variant": "conv3x3_wd9_tail_kernel<4, 4>" if wd9 else "conv3x3_wd_kernel<1, 4, 4, 4, 0, 2>",
+                        "shape": f"N{N} {H}x{W} Cin{Cin} Cout256->{tail_cout} k3+k1 s1 res{int(residual is not None)} f320",
                         "flops": 2.0 * M * 256 * 9 * Cin + 2.0 * M * tail_cout * 256,
                         "bytes": float(M * Cin * 2 + 256 * 9 * Cin * 2 + tail_cout * 256 * 2 + M * tail_cout * 2 * (2 if residual is not None else 1)),
                         "replay": (lambda: bottleneck_tail_wd(x, packed3x3, bias3x3, packed_tail, tail_bias, residual, tail_cout, out=out))})

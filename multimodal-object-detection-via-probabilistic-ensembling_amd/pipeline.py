@@ -9,6 +9,7 @@ streams is slower - 651 at 2 sub-batches, 612 at 4 - smaller launches tile worse
 import torch
 
 from . import fusion as F
+from . import layers as L
 
 
 class FramePairPipeline:
@@ -87,6 +88,15 @@ class FramePairPipeline:
     def __call__(self, frames_per_detector, out_sizes, resize_to):
         """frames_per_detector[d]: the batch for detector d ([B,H,W,C] uint8/float tensor or list of tensors).
         Returns (list of per-detector result dicts, fused dict of fusion.fuse_detections)."""
+        # the library's persistent kernels would otherwise hold every CU for their whole duration and shut the other stream out
+        # (the setting applies to launches ISSUED while it holds: everything this call enqueues)
+        L.set_concurrent_streams(len(self.streams) if self.streams else 1)
+        try:
+            return self._run(frames_per_detector, out_sizes, resize_to)
+        finally:
+            L.set_concurrent_streams(1)
+
+    def _run(self, frames_per_detector, out_sizes, resize_to):
         if self.staggered:
             return self._call_staggered(frames_per_detector, out_sizes, resize_to)
         if not self.concurrent:
