@@ -38,6 +38,12 @@ def main(cmd=None):
     cfg.MODEL.ROI_HEADS.NUM_CLASSES = 3
     cfg.DATASETS.TEST = (args.dataset_name,)
     dets = [read_j1(f) for f in files]
+    # the files are sharded with ONE index range: they must list the same images in the same order (the reference pairs by det_2's
+    # position too, demo_probEn.py:205-233, and silently mis-pairs otherwise)
+    for f, d in zip(files[:-1], dets[:-1]):
+        if d["image_id"] != dets[-1]["image_id"]:
+            raise ValueError(f"{f} and {files[-1]} do not list the same images in the same order ({len(d['image_id'])} vs "
+                             f"{len(dets[-1]['image_id'])} entries): late fusion pairs detections by position")
     mine = comm.shard_range(len(dets[-1]["image"]))
     dets = [shard_j1(d, mine) for d in dets]
     with open(val_json) as f:

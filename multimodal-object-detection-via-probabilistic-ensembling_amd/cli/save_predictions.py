@@ -18,6 +18,7 @@ from ..late_fusion import predictions_to_j1, write_j1
 from ..opt import config_parser
 
 THERMAL_MEAN = 135.438
+COCO_ZOO_WEIGHTS = "trained_models/Detectron2_pretrained/model_final_f6e8b1.pkl"   # demo_FLIR_save_predictions.py:60
 
 
 def build_cfg(args, config_dir=None):
@@ -29,7 +30,14 @@ def build_cfg(args, config_dir=None):
     cfg.MODEL.ROI_HEADS.NUM_CLASSES = 3
     cfg.MODEL.WEIGHTS = args.model_path or "synthetic://1"
     m = args.fusion_method
-    if m == "early_fusion":
+    if m == "rgb_only":
+        # demo_FLIR_save_predictions.py:59-61: the RGB detector is the COCO model-zoo R101-FPN (80 classes, zoo pickle), whatever
+        # --model_path says; its detections of classes > 2 are dropped when the predictions are written (:149, predictions_to_j1).
+        # The zoo model has no var_pred layer (the reference leaves it at its random initialisation): variance 1 here.
+        cfg.MODEL.ROI_HEADS.NUM_CLASSES = 80
+        if os.path.exists(COCO_ZOO_WEIGHTS):
+            cfg.MODEL.WEIGHTS = COCO_ZOO_WEIGHTS
+    elif m == "early_fusion":
         cfg.INPUT.FORMAT, cfg.INPUT.NUM_IN_CHANNELS = "BGRT", 4
         cfg.MODEL.PIXEL_MEAN = [103.53, 116.28, 123.675, THERMAL_MEAN]
         cfg.MODEL.PIXEL_STD = [1.0, 1.0, 1.0, 1.0]

@@ -333,6 +333,9 @@ extern "C" int pe_proben_fuse_batch(const double* boxes, const double* scores, c
                  "pe_proben_fuse_batch: null output pointer");
     PE_CHECK_ARG(score_mode >= 0 && score_mode <= 3, "pe_proben_fuse_batch: bad score_mode %d", score_mode);
     PE_CHECK_ARG(box_mode >= 0 && box_mode <= 3, "pe_proben_fuse_batch: bad box_mode %d", box_mode);
+    // K <= 62: a wavefront keeps a cluster's per-class log-odds in lanes (K + background in 64 lanes).  Enough for every fusion the
+    // reference can run: prediction files of different class counts cannot be fused there either (prepare_data concatenates the
+    // `probs` arrays, demo_probEn.py:79-90), and the 80-class rgb_only file is evaluated on its own.
     PE_CHECK_ARG(num_classes >= 1 && num_classes <= 62, "pe_proben_fuse_batch: num_classes %d not in [1,62]",
                  num_classes);
     PE_CHECK_ARG(probs || (score_mode != PE_SCORE_PROBEN && score_mode != PE_SCORE_MAX),

@@ -288,13 +288,27 @@ class FLIREvaluator:
             # InferenceSampler shards are contiguous, so rank order IS dataset order and the table rank 0 evaluates is the
             # single-process table, bit for bit.
             comm.synchronize()
-            mine = [[r["image_id"], *r["bbox"], r["score"], r["category_id"]] for p in self._predictions for r in p.get("instances", [])]
-            rows = comm.gather_rows(torch.tensor(mine, dtype=torch.float64).reshape(-1, 7))
-            seen = comm.gather_rows(torch.tensor([[float(len(self._predictions))]], dtype=torch.float64))
-            if not comm.is_main_process():
-                return {}
-            coco = [{"image_id": int(r[0]), "category_id": int(r[6]), "bbox": [r[1], r[2], r[3], r[4]], "score": r[5]} for r in rows.tolist()]
-            self._predictions = [{"image_id": -1, "instances": coco}] if int(seen.sum().item()) > 0 else []
+            flat = [r for p in self._predictions for r in p.get("instances", [])]
+            # image ids travel as float64: exact for integers below 2^53.  Anything else (string ids, huge ids - the reference pickles
+            # arbitrary dicts, so they worked there) takes the pickled gloo gather instead; the choice is made by ALL ranks together.
+            numeric = all(isinstance(r["image_id"], (int, np.integer)) and not isinstance(r["image_id"], bool) and abs(int(r["image_id"])) < 2 ** 53
+                          for r in flat)
+            numeric = all(comm.all_gather(bool(numeric)))
+            if numeric:
+                mine = [[r["image_id"], *r["bbox"], r["score"], r["category_id"]] for r in flat]
+                rows = comm.gather_rows(torch.tensor(mine, dtype=torch.float64).reshape(-1, 7))
+                seen = comm.gather_rows(torch.tensor([[float(len(self._predictions))]], dtype=torch.float64))
+                if not comm.is_main_process():
+                    return {}
+                coco = [{"image_id": int(r[0]), "category_id": int(r[6]), "bbox": [r[1], r[2], r[3], r[4]], "score": r[5]} for r in rows.tolist()]
+                n_seen = int(seen.sum().item())
+            else:
+                parts = comm.gather((flat, len(self._predictions)), dst=0)       # FLIR_evaluation.py:124-131
+                if not comm.is_main_process():
+                    return {}
+                coco = [r for part, _ in parts for r in part]
+                n_seen = sum(n for _, n in parts)
+            self._predictions = [{"image_id": -1, "instances": coco}] if n_seen > 0 else []
         if len(self._predictions) == 0:
             self._logger.warning("[FLIREvaluator] Did not receive valid predictions.")
             return {}

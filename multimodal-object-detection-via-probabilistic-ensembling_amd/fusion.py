@@ -173,11 +173,14 @@ def check_candidate_overflow(result):
     """Raise if a box head met more (proposal, class) candidates above SCORE_THRESH_TEST than its NMS stage holds
     (rcnn._roi_heads: cand_total > cand_max) - the device-to-device routes (forward_batch -> FramePairPipeline ->
     fuse_detections) would otherwise lose those detections silently, in proposal order, where the reference keeps all.
-    `result`: a forward_batch dict or a fuse_detections dict.  Synchronises with the device: call it where the consumer
-    reads results anyway (GeneralizedRCNN.to_instances does the same check for the Instances route)."""
+    `result`: a forward_batch dict or a fuse_detections dict.  Synchronises with the DEVICE (not just the current stream: the
+    counters are written on the detectors' side streams of FramePairPipeline, which the caller's stream need not have waited for):
+    call it where the consumer reads results anyway (GeneralizedRCNN.to_instances does the same check for the Instances route)."""
     src = result.get("cand_overflow_src")
     if src is None and "cand_total" in result:
         src = [(result["cand_total"], result["cand_max"])]
+    if src and any(t.is_cuda for t, _ in src):
+        torch.cuda.synchronize(src[0][0].device)
     for tot, cmax in src or []:
         worst = int(tot.max())
         if worst > cmax:

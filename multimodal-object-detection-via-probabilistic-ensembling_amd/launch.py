@@ -30,11 +30,12 @@ def free_port():
         return s.getsockname()[1]
 
 
-def launch_command(argv, nproc, port, script=None, module=None):
-    """The `torch.distributed.run` command line for `nproc` local ranks of a script path or a `-m` module."""
+def launch_command(argv, nproc, port=None, script=None, module=None):
+    """The `torch.distributed.run` command line for `nproc` local ranks of a script path or a `-m` module.  port None: the launcher
+    binds its own rendezvous port on 127.0.0.1 (`--standalone`; no bind-release-rebind race with other jobs on a busy host)."""
     assert (script is None) != (module is None), "give a script path or a module name"
-    head = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
-            "--master-addr", "127.0.0.1", "--master-port", str(port)]
+    head = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}"]
+    head += ["--standalone", "--local-addr", "127.0.0.1"] if port is None else ["--master-addr", "127.0.0.1", "--master-port", str(port)]
     return head + (["-m", module] if module else [script]) + list(argv)
 
 
@@ -62,7 +63,7 @@ def maybe_self_launch(world_size, argv, module=None, script=None, device="cuda",
         if have < world_size:
             sys.exit(f"{what}: --world-size {world_size} requested but only {have} GPU(s) are visible; refusing to run "
                      f"{world_size} ranks on fewer devices")
-    sys.exit(subprocess.call(launch_command(argv, world_size, free_port(), script=script, module=module), env=launch_env()))
+    sys.exit(subprocess.call(launch_command(argv, world_size, None, script=script, module=module), env=launch_env()))
 
 
 def init_distributed(device="cuda", expect_world=None):
@@ -74,6 +75,13 @@ def init_distributed(device="cuda", expect_world=None):
     share = cuda and os.environ.get("PROBEN_DIST_BACKEND", "nccl") == "gloo"
     if share:
         local %= max(torch.cuda.device_count(), 1)
+    if cuda and not share:
+        # an external launcher (torchrun with more ranks than GPUs) must get the same refusal as the self-launch path, not an
+        # "invalid device ordinal" from set_device or an RCCL error from two ranks sharing a device
+        have = torch.cuda.device_count()
+        if local >= have:
+            sys.exit(f"rank {rank}: LOCAL_RANK {local} but only {have} GPU(s) are visible; refusing to run {world} ranks on fewer devices "
+                     "(one process per GPU; PROBEN_DIST_BACKEND=gloo lets ranks share a device for testing)")
     dev = torch.device("cuda", local) if cuda else torch.device("cpu")
     if cuda:
         torch.cuda.set_device(local)
@@ -94,10 +102,16 @@ def init_distributed(device="cuda", expect_world=None):
     return rank, world, dev
 
 
-def shutdown():
+def shutdown(barrier=True):
+    """Leave the process group.  `barrier=False` for a rank that exits on an error path (or has nothing left to do while rank 0
+    still writes results): the others must not sit in a collective that this rank never joins."""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():
-        dist.barrier()
+        if barrier:
+            try:
+                dist.barrier()
+            except Exception:       # a peer has gone: nothing left to synchronise with
+                pass
         dist.destroy_process_group()
     from . import comm
     comm._object_group.cache_clear()

@@ -17,11 +17,25 @@ STAGE_BLOCKS = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3), 152: (3, 8, 36, 3)}  # bac
 
 
 def load_state_dict_file(path):
-    """`.pth` written by torch.save: a raw state dict or {"model": state_dict} (checkpoint/detection_checkpoint.py)."""
-    obj = torch.load(path, map_location="cpu")
-    if isinstance(obj, dict) and "model" in obj and isinstance(obj["model"], dict):
-        obj = obj["model"]
-    return {k: (v if isinstance(v, torch.Tensor) else torch.as_tensor(v)) for k, v in obj.items()}
+    """A checkpoint file -> {reference key: tensor} (checkpoint/detection_checkpoint.py:27-45):
+      * `.pth` written by torch.save: a raw state dict or {"model": state_dict};
+      * `.pkl` in the detectron2 model-zoo format: {"model": {key: ndarray}, "__author__": ...} with the state dict's own key names
+        (trained_models/Detectron2_pretrained/model_final_f6e8b1.pkl of demo_FLIR_save_predictions.py:59-61, the COCO R101-FPN
+        detector behind `--fusion_method rgb_only`).  A Caffe2 / Detectron1 pickle ("blobs", or no "__author__") needs the
+        reference's name-matching heuristics (c2_model_loading.py), which are not part of the inference path: refused."""
+    if str(path).endswith(".pkl"):
+        import pickle
+        with open(path, "rb") as f:
+            data = pickle.load(f, encoding="latin1")
+        if not (isinstance(data, dict) and "model" in data and "__author__" in data):
+            raise ValueError(f"{path}: not a detectron2 model-zoo pickle (Caffe2 / Detectron1 weights need the reference's "
+                             "key-matching heuristics; convert them with the reference and save a .pth)")
+        obj = data["model"]
+    else:
+        obj = torch.load(path, map_location="cpu")
+        if isinstance(obj, dict) and "model" in obj and isinstance(obj["model"], dict):
+            obj = obj["model"]
+    return {k: (v if isinstance(v, torch.Tensor) else torch.as_tensor(v)) for k, v in obj.items() if not k.endswith("_momentum")}
 
 
 def infer_depth(sd, prefix="backbone.bottom_up"):

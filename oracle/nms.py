@@ -13,9 +13,15 @@ demo/FLIR/demo_probEn.py:64.  This restates torchvision's published algorithm:
                boxes.numel() <= 4000 on CPU / 20000 on GPU, else one nms per class
                ("vanilla"), result re-sorted by score descending.
 
-PARITY UNPINNED at this boundary: the reference's tests hold no NMS vectors and
-torchvision is absent from the build container; the algorithm above is anchored
-on the call sites only (tests/test_rpn.py pins it indirectly).
+PARITY: INDIRECTLY PINNED (round 4).  torchvision itself is absent from the reference tree and from the build container, but the
+reference holds two statements of horizontal greedy NMS that its own tests equate with torchvision's: the Python
+`reference_horizontal_nms` (tests/test_nms_rotated.py:11-33, asserted == nms_rotated at 0 degrees, :89-101) and the C++ rotated
+kernel at 0 degrees (layers/csrc/nms_rotated/nms_rotated_cpu.cpp:7-60 + box_iou_rotated_utils.h:315-340, asserted ==
+torchvision batched_nms for IoU 0.2 / 0.5 / 0.8, :45-66).  tests/golden/gen_nms.py EXECUTES both on this repo's fixtures (a 4 624-box
+RPN-like set, a dense 1 500-box set, the reference test's own recipe; IoU 0.5 / 0.7) and tests/test_oracle_nms.py requires this
+file to reproduce their keep lists index for index (the HIP kernel likewise, tests/test_ops_gpu.py).  Not covered by reference-held
+code: the coordinate-trick / per-class dispatch thresholds of batched_nms (torchvision's, restated) and the order of exactly tied
+scores (the fixtures are tie-free).
 Tie rule: score descending, then index ascending (stable descending sort).
 """
 import numpy as np

@@ -17,21 +17,25 @@ def iou_matrix(a, b):
     return inter / (aa[:, None] + ab[None, :] - inter + 1e-12)
 
 
-def run_pair(depth=50, hw=(480, 608), n_images=2, seed=1, in_channels=3):
+def run_pair(depth=50, hw=(480, 608), n_images=2, seed=1, in_channels=3, num_classes=3, cls_std=0.1, score_thresh=0.5, sd_edit=None):
     import proben_amd  # noqa: F401
     from oracle import detector as D
     from proben_amd.rcnn import DetectorConfig, GeneralizedRCNN
     from proben_amd.synthetic import synthetic_images, synthetic_state_dict
-    sd = synthetic_state_dict(depth, 3, in_channels, seed=seed)
+    sd = synthetic_state_dict(depth, num_classes, in_channels, seed=seed, cls_std=cls_std)
+    if sd_edit is not None:
+        sd_edit(sd)
     imgs = synthetic_images(n_images, height=hw[0], width=hw[1], channels=in_channels, seed=0)
     x = [torch.from_numpy(im).permute(2, 0, 1).float().contiguous() for im in imgs]
     x[-1] = x[-1][:, : hw[0] - 40, : hw[1] - 50].contiguous()  # different size -> padding inside the batch
     outs = [(im.shape[1] // 2, im.shape[2] // 2) for im in x]
     torch.set_num_threads(8)
-    want, inter = D.forward(x, sd, D.DetectorSpec(depth=depth, in_channels=in_channels), out_sizes=outs, return_intermediates=True)
+    want, inter = D.forward(x, sd, D.DetectorSpec(depth=depth, in_channels=in_channels, num_classes=num_classes, score_thresh=score_thresh),
+                            out_sizes=outs, return_intermediates=True)
     fmt = {3: "BGR", 4: "BGRT", 6: "BGRTTT"}[in_channels]
     mean = (103.53, 116.28, 123.675) + (135.438,) * (in_channels - 3)
-    model = GeneralizedRCNN(DetectorConfig(input_format=fmt, pixel_mean=mean, pixel_std=(1.0,) * in_channels), sd)
+    model = GeneralizedRCNN(DetectorConfig(input_format=fmt, pixel_mean=mean, pixel_std=(1.0,) * in_channels, num_classes=num_classes,
+                                           score_thresh=score_thresh), sd)
     det = model.forward_batch([t.cuda() for t in x], out_sizes=outs, keep_intermediates=True)
     torch.cuda.synchronize()
     return want, inter, det, model
@@ -81,6 +85,29 @@ def check_pair(want, inter, det, min_match=0.85, feat_rel=2.5e-3):   # measured 
 def test_r50_forward_matches_oracle():
     want, inter, det, _ = run_pair(50)
     check_pair(want, inter, det)
+
+
+def test_rgb_only_variant_80_classes_matches_oracle_and_keeps_classes_0_to_2():
+    """demo_FLIR_save_predictions.py:59-61,149: the RGB detector of the two-detector configuration is the COCO model (K = 80:
+    predictor GEMM with 81 + 320 + 1 columns, 80-class decode / threshold / class-aware NMS), of whose detections only classes
+    0 .. 2 (person, bicycle, car) are written to the prediction file."""
+    from proben_amd.late_fusion import predictions_to_j1
+    def prefer_a_few_classes(sd):    # a head that fires on classes 0, 2, 5, 17 (~350 candidates per image, mostly classes > 2)
+        b = sd["roi_heads.box_predictor.cls_score.bias"]
+        b[[0, 2, 5, 17]] += 4.0
+        b[80] += 5.0
+    want, inter, det, model = run_pair(50, hw=(320, 416), num_classes=80, cls_std=0.04, seed=4, sd_edit=prefer_a_few_classes)
+    assert det["class_logits"].shape[-1] == 81 and det["prob_score"].shape[-1] == 80
+    n_det = int(det["counts"].sum())
+    assert n_det >= 10 and sum(len(w["scores"]) for w in want) >= 10, "the synthetic 80-class head must fire"
+    assert int(det["classes"][0, : int(det["counts"][0])].max()) > 2, "classes beyond the first three must occur for the filter to matter"
+    check_pair(want, inter, det)
+    insts = model.to_instances(det)
+    j1 = predictions_to_j1(["a.jpg", "b.jpg"], [0, 1], insts)
+    kept = sum(len(c) for c in j1["classes"])
+    assert all(c <= 2 for cs in j1["classes"] for c in cs)
+    assert kept == sum(int((det["classes"][i, : int(det["counts"][i])] <= 2).sum()) for i in range(2))
+    assert all(len(p) == 80 for ps in j1["probs"] for p in ps) and all(len(l) == 81 for ls in j1["class_logits"] for l in ls)
 
 
 @pytest.mark.parametrize("in_channels", [4, 6])

@@ -196,6 +196,43 @@ def test_j1_prediction_schema(tmp_path):
     assert late_fusion.read_j1(str(p)) == json.loads(json.dumps(pred))
 
 
+def test_model_zoo_pickle_reader_and_rgb_only_cfg(tmp_path, monkeypatch):
+    """checkpoint/detection_checkpoint.py:27-45: a detectron2 model-zoo `.pkl` ({"model": ndarrays, "__author__"}) loads into the same
+    state dict a `.pth` gives; a Caffe2 / Detectron1 pickle is refused (its key-matching heuristics are not on the inference path).
+    demo_FLIR_save_predictions.py:59-61: `rgb_only` is the 80-class COCO detector with the zoo weights."""
+    import pickle
+    from proben_amd.cli.save_predictions import COCO_ZOO_WEIGHTS, build_cfg
+    from proben_amd.opt import config_parser
+    from proben_amd.synthetic import synthetic_state_dict
+    from proben_amd.weights import load_state_dict_file
+    sd = synthetic_state_dict(50, 80, 3, seed=3)
+    sd = {k: v for k, v in sd.items() if "var_pred" not in k}       # the zoo model has no variance head
+    zoo = tmp_path / "model_final_f6e8b1.pkl"
+    with open(zoo, "wb") as f:
+        pickle.dump({"model": {k: v.numpy() for k, v in sd.items()}, "__author__": "Detectron2 Model Zoo"}, f, protocol=2)
+    got = load_state_dict_file(str(zoo))
+    assert set(got) == set(sd) and all(torch.equal(got[k], sd[k]) for k in sd)
+    assert got["roi_heads.box_predictor.cls_score.weight"].shape[0] == 81 and got["roi_heads.box_predictor.bbox_pred.weight"].shape[0] == 320
+    pth = tmp_path / "m.pth"
+    torch.save({"model": sd}, pth)
+    again = load_state_dict_file(str(pth))
+    assert all(torch.equal(again[k], sd[k]) for k in sd)
+    c2 = tmp_path / "R-101.pkl"
+    with open(c2, "wb") as f:
+        pickle.dump({"blobs": {"conv1_w": np.zeros((64, 3, 7, 7), np.float32)}}, f, protocol=2)
+    with pytest.raises(ValueError, match="model-zoo"):
+        load_state_dict_file(str(c2))
+    # cfg of the variant: 80 classes; the zoo weights when the reference's relative path exists, else --model_path / synthetic
+    cfg = build_cfg(config_parser(["--dataset_path", "x", "--fusion_method", "rgb_only"]))
+    assert cfg.MODEL.ROI_HEADS.NUM_CLASSES == 80 and cfg.INPUT.FORMAT == "BGR" and list(cfg.MODEL.PIXEL_MEAN) == [103.53, 116.28, 123.675]
+    monkeypatch.chdir(tmp_path)
+    os.makedirs(os.path.dirname(COCO_ZOO_WEIGHTS))
+    os.replace(zoo, COCO_ZOO_WEIGHTS)
+    cfg = build_cfg(config_parser(["--dataset_path", "x", "--fusion_method", "rgb_only", "--model_path", "ignored.pth"]))
+    assert cfg.MODEL.WEIGHTS == COCO_ZOO_WEIGHTS
+    assert build_cfg(config_parser(["--dataset_path", "x", "--fusion_method", "thermal_only"])).MODEL.ROI_HEADS.NUM_CLASSES == 3
+
+
 def test_kaist_rows_byte_exact_vs_reference_writer(golden_dir):
     """K1: text rows and variance file of the KAIST driver against tests/golden/kaist_rows.json, produced by executing
     the reference's own writer statements (demo/KAIST/demo_LAMR_KAIST.py:128-142) - byte for byte."""

@@ -460,6 +460,27 @@ def rand_boxes(g, n, span=600.0, wh=120.0):
     return torch.cat([xy, xy + torch.rand(n, 2, generator=g) * wh + 1], 1)
 
 
+@pytest.mark.parametrize("name", ["rpn", "det", "uniform"])
+@pytest.mark.parametrize("thr", [0.5, 0.7])
+def test_nms_reproduces_the_references_own_nms(L, golden_dir, name, thr):
+    """csrc/nms.hip against keep lists computed by the reference's OWN statements of horizontal greedy NMS (tests/golden/gen_nms.py:
+    tests/test_nms_rotated.py:11-33 in Python and layers/csrc/nms_rotated/nms_rotated_cpu.cpp at 0 degrees, which the reference's
+    tests equate with torchvision's nms / batched_nms): index-exact, through nms and through batched_nms in both dispatch modes."""
+    z = np.load(os.path.join(golden_dir, "nms_reference.npz"))
+    b, s = torch.from_numpy(z[name + "_boxes"]).cuda(), torch.from_numpy(z[name + "_scores"]).cuda()
+    want = z[f"{name}_keep_python_{thr}"]
+    np.testing.assert_array_equal(want, z[f"{name}_keep_rotated_{thr}"])
+    np.testing.assert_array_equal(L.nms(b, s, thr).cpu().numpy(), want)
+    # four interleaved copies of the set as four classes: every class must keep exactly the single-class list
+    n = len(s)
+    bb, ss = b.repeat(4, 1), s.repeat(4)
+    idx = torch.arange(4, device="cuda").repeat_interleave(n)
+    keep = L.batched_nms(bb, ss, idx, thr).cpu().numpy()          # 4 n x 4 > 20000 elements for the two larger sets: per-class mode
+    for c in range(4):
+        mine = keep[(keep >= c * n) & (keep < (c + 1) * n)] - c * n
+        np.testing.assert_array_equal(mine, want)
+
+
 @pytest.mark.parametrize("case", [(48, 60, 75, 94, 4), (64, 64, 31, 47, 4), (90, 30, 135, 30, 3)])
 def test_preprocess_float_resize_vs_opencv_restatement(L, case):
     """4- / 6-channel fusion inputs are floating point and go through cv2.resize in the reference; the kernel follows
