@@ -236,8 +236,23 @@ def roofline_leg(step, layers_path="", reps=10):
     except Exception:
         traffic = {}
 
+    def find_traffic(kernel):
+        """exact kernel name, else every instantiation of the same kernel template in the newest profile (the bench table groups the
+        pure wd9 launches of all image widths under one label; rocprof names them per template argument): launch-weighted mean"""
+        hit = traffic.get(kernel.replace(" ", ""))
+        if hit:
+            return hit
+        base = kernel.split("<")[0]
+        same = [(v, src) for k, (v, src) in traffic.items() if k.split("<")[0].split("::")[-1] == base]
+        if not same:
+            return None
+        newest = max(src for _, src in same)
+        same = [v for v, src in same if src == newest]
+        n = sum(v.get("launches", 1) for v in same)
+        return {"hbm_mb_per_launch": round(sum(v["hbm_mb_per_launch"] * v.get("launches", 1) for v in same) / n, 1)}, newest
+
     def with_traffic(d):
-        hit = traffic.get(d["kernel"].replace(" ", ""))
+        hit = find_traffic(d["kernel"])
         if hit:
             v, src = hit
             d["traffic"] = round(v["hbm_mb_per_launch"] * 1e6)   # HBM bytes per launch (compare: algorithmic_mbytes_per_launch)

@@ -33,7 +33,7 @@ def main():
     import proben_amd  # noqa: F401
     from oracle import detector as D
     from proben_amd.data import resize_shortest_edge_shape
-    from test_parity_map_gpu import coco_stats, load_fixture
+    from parity_map import coco_stats, load_fixture
     torch.set_num_threads(args.threads)
     z, sd, frames, gts = load_fixture(os.path.join(ROOT, "tests", "golden"))
     n = min(args.frames, len(frames))

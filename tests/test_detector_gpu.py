@@ -102,7 +102,7 @@ def test_rgb_only_variant_80_classes_matches_oracle_and_keeps_classes_0_to_2():
     assert n_det >= 10 and sum(len(w["scores"]) for w in want) >= 10, "the synthetic 80-class head must fire"
     assert int(det["classes"][0, : int(det["counts"][0])].max()) > 2, "classes beyond the first three must occur for the filter to matter"
     check_pair(want, inter, det)
-    insts = model.to_instances(det)
+    insts = [o["instances"] for o in model.to_instances(det)]
     j1 = predictions_to_j1(["a.jpg", "b.jpg"], [0, 1], insts)
     kept = sum(len(c) for c in j1["classes"])
     assert all(c <= 2 for cs in j1["classes"] for c in cs)
