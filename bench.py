@@ -431,7 +431,10 @@ def main(argv=None):
                        "end_to_end_tflops": round(value * cfg["gflop"] / 1e3, 1) if cfg["gflop"] else None,
                        "input_residency": ("frames resident in HBM before the timed region (no H2D inside it)" if feeder is None else
                                            "frames in pinned host memory; double-buffered H2D upload of every batch INSIDE the timed region"),
-                       "timed_seconds": round(dt, 2), "schedule": sched},
+                       "timed_seconds": round(dt, 2), "schedule": sched,
+                       "persistent_kernels": ("csrc/conv_wd9*.h: one workgroup per CU when a launch has the chip to itself (one stream, and the per-kernel "
+                                              "replay of `roofline`); the fused-tail kernel takes 256 / streams workgroups while the detectors run on "
+                                              f"{1 if args.serial_detectors else len(models)} stream(s) (pe_conv_wd_set_concurrent_streams, DESIGN.md 10.4)")},
         }
         if world > 1 or comm_active():
             line["config"]["collective"] = "one all_gather_into_tensor of the fused rows per step (RCCL)" + ("" if world > 1 else

@@ -35,7 +35,8 @@ static bool wd9_tail_takes(int H, int W, int Cin, int tail_cout) { return (g_wd9
 
 int wd9_bottleneck_tail(ConvWdArgs a, hipStream_t st) {
     if (!wd9_tail_takes(a.H, a.W, a.Cin, a.tail_cout)) return PE_ERR_UNSUPPORTED;
-    return wd9t::launch<4, 4>(a, st, g_wd9_tail_wgs);
+    // start skew 8 k cycles: measured -3.5 % on the long pole's cycles, ~-2 % wall (profiles/r04_wd9_tail_probe_4.txt)
+    return wd9t::launch<4, 4>(a, st, g_wd9_tail_wgs, nullptr, 8000);
 }
 }  // namespace pe
 

@@ -51,7 +51,7 @@ static_assert(LDS_BYTES == 160 * 1024, "the layout uses the whole LDS of a CU");
 // ABL (measurement builds, results wrong): 1 = no output stores, 2 = no shortcut loads, 8 = skip phase B
 // DBG: wave 0 of every workgroup stamps s_memtime at kernel start and per tile: start, end of phase A, end of phase B
 template <int DEPTH = 4, int DB = 2, int ABL = 0, int DBG = 0>
-__global__ __launch_bounds__(THREADS, 1) void conv3x3_wd9_tail_kernel(pe::ConvWdArgs a, unsigned long long* dbg) {
+__global__ __launch_bounds__(THREADS, 1) void conv3x3_wd9_tail_kernel(pe::ConvWdArgs a, unsigned long long* dbg, int skew) {
     static_assert(12 % DEPTH == 0 && 16 % DB == 0, "prefetch depths divide the K-steps of a group / a chunk");
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     typedef __attribute__((address_space(3))) unsigned char lds_byte;
@@ -70,6 +70,13 @@ __global__ __launch_bounds__(THREADS, 1) void conv3x3_wd9_tail_kernel(pe::ConvWd
     const int lid = (nwg % 8 == 0) ? (blockIdx.x % 8) * (nwg / 8) + blockIdx.x / 8 : blockIdx.x;
     const int r_begin = (int)((long long)lid * R / nwg), r_end = (int)((long long)(lid + 1) * R / nwg);
     if (r_begin >= r_end) return;
+    // Start skew: all workgroups start together and would reach their HBM-heavy phase B together (420 MB in lock-step = the chip's
+    // whole bandwidth while it lasts).  When the rows do not divide evenly, the workgroups with the SMALLER share have slack against
+    // the launch's long pole; they spend it up front, spread over eight start times `skew` cycles apart.
+    if (skew > 0 && R % nwg != 0 && R / nwg >= 6 && r_end - r_begin == R / nwg) {      // (7 x skew must stay below the time of a 1-row tile, ~59 k cycles)
+        const long long until = (long long)__builtin_readcyclecounter() + (long long)((lid * 5) & 7) * skew;
+        while ((long long)__builtin_readcyclecounter() < until) __builtin_amdgcn_s_sleep(32);
+    }
 
     auto slot_off = [&](int s) { return s == 0 ? S0_OFF : (s == 1 ? S1_OFF : 0); };
 
@@ -378,13 +385,13 @@ __global__ __launch_bounds__(THREADS, 1) void conv3x3_wd9_tail_kernel(pe::ConvWd
 inline bool geometry_ok(int H, int W, int Cin, int tail_cout) { return W == 64 && H >= 3 && Cin % 64 == 0 && Cin > 0 && tail_cout % 256 == 0; }
 
 template <int DEPTH = 4, int DB = 2, int ABL = 0, int DBG = 0>
-inline int launch(pe::ConvWdArgs a, hipStream_t st, int workgroups = 256, unsigned long long* dbg = nullptr) {
+inline int launch(pe::ConvWdArgs a, hipStream_t st, int workgroups = 256, unsigned long long* dbg = nullptr, int skew = 0) {
     if (!geometry_ok(a.H, a.W, a.Cin, a.tail_cout)) return PE_ERR_UNSUPPORTED;
     const int R = a.N * a.H;
     int nwg = (R + 2) / 3;
     if (nwg > workgroups) nwg = workgroups;
     PE_ENSURE_LDS((conv3x3_wd9_tail_kernel<DEPTH, DB, ABL, DBG>), (size_t)LDS_BYTES, "conv3x3_wd9_tail");
-    hipLaunchKernelGGL((conv3x3_wd9_tail_kernel<DEPTH, DB, ABL, DBG>), dim3(nwg), dim3(THREADS), LDS_BYTES, st, a, dbg);
+    hipLaunchKernelGGL((conv3x3_wd9_tail_kernel<DEPTH, DB, ABL, DBG>), dim3(nwg), dim3(THREADS), LDS_BYTES, st, a, dbg, skew);
     return PE_OK;
 }
 

@@ -142,20 +142,16 @@ int main(int argc, char** argv) {
             fflush(stdout);
         };
         time_it("shipped tail wd<1,4,tpx4,d4,HEAD 2>", [&] { return wd::launch_conv3x3_wd<1, 4, 4, 4, 0, 2>(a, 0); }, true, true);
-#define TAILV(label, DA, DBv)                                                                                   \
-        time_it(label, [&] { return wd9t::launch<DA, DBv, 0, 0>(a, 0); }, true, false);                          \
-        timeline(label, [&](unsigned long long* d) { return wd9t::launch<DA, DBv, 0, 1>(a, 0, 256, d); });
-        TAILV("wd9 tail dA4 dB2", 4, 2)
-        TAILV("wd9 tail dA4 dB4", 4, 4)
-        TAILV("wd9 tail dA4 dB8", 4, 8)
-        TAILV("wd9 tail dA6 dB4", 6, 4)
-        TAILV("wd9 tail dA6 dB8", 6, 8)
-        time_it("  abl dA6 dB8: no stores", [&] { return wd9t::launch<6, 8, 1, 0>(a, 0); }, false, false);
-        timeline("  abl dA6 dB8: no stores", [&](unsigned long long* d) { return wd9t::launch<6, 8, 1, 1>(a, 0, 256, d); });
-        time_it("  abl dA6 dB8: no shortcut", [&] { return wd9t::launch<6, 8, 2, 0>(a, 0); }, false, false);
-        timeline("  abl dA6 dB8: no shortcut", [&](unsigned long long* d) { return wd9t::launch<6, 8, 2, 1>(a, 0, 256, d); });
-        time_it("  abl dA6 dB8: phase A only", [&] { return wd9t::launch<6, 8, 8, 0>(a, 0); }, false, false);
-        timeline("  abl dA6 dB8: phase A only", [&](unsigned long long* d) { return wd9t::launch<6, 8, 8, 1>(a, 0, 256, d); });
+#define TAILV(label, DA, DBv, SK)                                                                                \
+        time_it(label, [&] { return wd9t::launch<DA, DBv, 0, 0>(a, 0, 256, nullptr, SK); }, true, false);        \
+        timeline(label, [&](unsigned long long* d) { return wd9t::launch<DA, DBv, 0, 1>(a, 0, 256, d, SK); });
+        TAILV("wd9 tail dA4 dB4", 4, 4, 0)
+        TAILV("wd9 tail dA4 dB4 skew 2k", 4, 4, 2000)
+        TAILV("wd9 tail dA4 dB4 skew 4k", 4, 4, 4000)
+        TAILV("wd9 tail dA4 dB4 skew 6k", 4, 4, 6000)
+        TAILV("wd9 tail dA4 dB4 skew 8k", 4, 4, 8000)
+        TAILV("wd9 tail dA4 dB4 skew 12k", 4, 4, 12000)
+        TAILV("wd9 tail dA4 dB4 (again)", 4, 4, 0)
         hipFree(din); hipFree(dw); hipFree(dwp); hipFree(dw3); hipFree(dw3p); hipFree(dres); hipFree(dout); hipFree(db); hipFree(db3);
     }
     return 0;
