@@ -10,8 +10,13 @@
 
 namespace pe {
 // bit 0: the pure 3x3 kernel takes launches of at least kWd9MinTiles tiles; bit 1: ... whenever the geometry allows (tests);
-// bit 2: the fused bottleneck tail of image width 64 runs on conv_wd9_tail.h
-int g_wd9_mode = 1 | 4;
+// bit 2: the fused bottleneck tail of image width 64 runs on conv_wd9_tail.h.
+// Default 1: the pure kernel is worth +1 % in every pipeline of bench.py (profiles/r04_pipeline_ab_*.txt).  The tail kernel is 8-14 %
+// faster than the two-wave tail as a launch of its own at batch 32, but a 512-register / 160-KiB workgroup owns its CU: the other
+// detector's kernels can no longer co-reside with it, and whole frame-pair pipelines measure -0.5 .. -5 % with it (two R101 detectors on
+// two streams: -3 % at 256 workgroups, break-even at 128; thermal-only batch 16: -3 %; three detectors: -5 %).  It is therefore opt-in
+// (pe_test_set_wd9_mode(5), `bench.py --wd9-mode 5`), like a cuDNN algorithm that wins its own benchmark and loses the network's.
+int g_wd9_mode = 1;
 // workgroups of the persistent kernels (pure 3x3, fused tail): one per CU when a launch has the chip to itself; the two-detector
 // pipeline runs the detectors on two streams, and a kernel that occupies every CU for its whole duration shuts the other stream out
 int g_wd9_wgs = 256, g_wd9_tail_wgs = 256;

@@ -10,7 +10,7 @@ extern "C" {
  *                                16: 256x256 kernel for every eligible launch
  *   reuse3x3 (default 1): 1 = kw-reuse 3x3 kernel, 0 = generic per-tap 3x3 kernel */
 int pe_test_set_conv_policy(int tile_bits, int reuse3x3);
-/* Which generation of the weights-direct kernels takes a launch.  Bit mask (default 5):
+/* Which generation of the weights-direct kernels takes a launch.  Bit mask (default 1; the tail kernel is opt-in, csrc/conv_wd9.hip):
  *   1 = pure 3x3: conv_wd9.h for launches of >= 128 tiles of 256 pixels (same bits as conv_wd.h)   2 = ... whenever the geometry allows
  *   4 = fused bottleneck tail: conv_wd9_tail.h for image width 64 (chosen by geometry only)          0 = conv_wd.h only */
 int pe_test_set_wd9_mode(int mode);

@@ -201,10 +201,10 @@ def test_conv3x3_wd9_is_bit_identical_to_conv_wd(L, case):
     try:
         hooks.pe_test_set_wd9_mode(0)
         old = run()
-        hooks.pe_test_set_wd9_mode(2 | 4)
+        hooks.pe_test_set_wd9_mode(2)
         new1, new2 = run(), run()
     finally:
-        hooks.pe_test_set_wd9_mode(1 | 4)
+        hooks.pe_test_set_wd9_mode(1)
     torch.cuda.synchronize()
     assert torch.equal(new1, new2)
     assert torch.equal(new1, old)
@@ -278,7 +278,7 @@ def test_fused_bottleneck_tail_wd9_geometry(L, shape):
     never by batch size)."""
     from proben_amd import _lib
     N, H, W, Cin, CoutT, with_res = shape
-    _lib.test_hooks().pe_test_set_wd9_mode(1 | 4)
+    _lib.test_hooks().pe_test_set_wd9_mode(1 | 4)      # the tail kernel is opt-in (csrc/conv_wd9.hip)
     assert _lib.test_hooks().pe_test_wd9_tail_takes(H, W, Cin, CoutT) == 1
     g = torch.Generator(device="cpu").manual_seed(41)
     x = torch.randn(N, Cin, H, W, generator=g).cuda().half().relu()
@@ -306,6 +306,12 @@ def test_fused_bottleneck_tail_wd9_geometry(L, shape):
     for n in (0, N - 1):
         one = L.bottleneck_tail_wd(xs[n:n + 1].contiguous(), p2, b2, p3, b3, None if r is None else r[n:n + 1].contiguous(), CoutT)
         assert torch.equal(one[0], outs[0][n])
+    # the number of workgroups (what pe_conv_wd_set_concurrent_streams changes) moves tile boundaries, never results
+    L.set_concurrent_streams(2)
+    half = L.bottleneck_tail_wd(xs, p2, b2, p3, b3, r, CoutT)
+    L.set_concurrent_streams(1)
+    assert torch.equal(half, outs[0])
+    _lib.test_hooks().pe_test_set_wd9_mode(1)
 
 
 @pytest.mark.parametrize("shape", [(2, 8, 64, True, True), (1, 7, 70, False, True), (3, 5, 32, False, False), (2, 13, 130, True, False), (1, 50, 64, False, True)])
