@@ -68,6 +68,7 @@ def parse(argv=None):
     ap.add_argument("--serial-detectors", action="store_true", help="run the detectors back to back on one stream")
     ap.add_argument("--wd9-tail-wgs", type=int, default=0, help="A/B: workgroups of the persistent fused-tail kernel (0 = the library's default)")
     ap.add_argument("--wd9-wgs", type=int, default=0, help="A/B: workgroups of the persistent pure 3x3 kernel (0 = the library's default)")
+    ap.add_argument("--roi-sort", type=int, default=1, help="0: ROIAlign takes the proposals in RPN order (A/B; identical results)")
     ap.add_argument("--wd9-mode", type=int, default=-1,
                     help="A/B (csrc/test_hooks.h): 0 = two-wave weights-direct kernels only (csrc/conv_wd.h), 1 = persistent one-wave-per-SIMD "
                          "kernel for the pure 3x3 launches, 4 = for the fused res4 tail, 5 = both; -1 = the library's default")
@@ -375,6 +376,9 @@ def main(argv=None):
     if args.wd9_tail_wgs > 0 or args.wd9_wgs > 0:
         from proben_amd import _lib
         _lib.test_hooks().pe_test_set_wd9_wgs(args.wd9_wgs, args.wd9_tail_wgs)
+    if not args.roi_sort:
+        from proben_amd import layers as _layers
+        _layers.ROI_SORT = False
     if args.wd9_mode >= 0:
         from proben_amd import _lib
         _lib.test_hooks().pe_test_set_wd9_mode(args.wd9_mode)
@@ -432,9 +436,10 @@ def main(argv=None):
                        "input_residency": ("frames resident in HBM before the timed region (no H2D inside it)" if feeder is None else
                                            "frames in pinned host memory; double-buffered H2D upload of every batch INSIDE the timed region"),
                        "timed_seconds": round(dt, 2), "schedule": sched,
-                       "persistent_kernels": ("csrc/conv_wd9*.h: one workgroup per CU when a launch has the chip to itself (one stream, and the per-kernel "
-                                              "replay of `roofline`); the fused-tail kernel takes 256 / streams workgroups while the detectors run on "
-                                              f"{1 if args.serial_detectors else len(models)} stream(s) (pe_conv_wd_set_concurrent_streams, DESIGN.md 10.4)")},
+                       "persistent_kernels": ("csrc/conv_wd9.h (pure 3x3, one 512-register workgroup per CU) takes the 256 -> 256 launches of >= 128 tiles; "
+                                              "csrc/conv_wd9_tail.h (fused res4 tail on the same structure) is "
+                                              + ("ON (--wd9-mode)" if args.wd9_mode >= 0 and args.wd9_mode & 4 else
+                                                 "opt-in and OFF here: faster as a launch of its own, slower in every pipeline (DESIGN.md 10.4)"))},
         }
         if world > 1 or comm_active():
             line["config"]["collective"] = "one all_gather_into_tensor of the fused rows per step (RCCL)" + ("" if world > 1 else

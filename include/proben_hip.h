@@ -282,6 +282,17 @@ int pe_roi_align_nhwc(const void* const* feats_host, const int32_t* feat_hw_host
                       const int32_t* counts, int32_t pooled_h, int32_t pooled_w, int32_t sampling_ratio,
                       int32_t aligned, void* output, int32_t* out_level, void* stream);
 
+/* The same, boxes form only ([N, per_image, 4] + counts), with the PROCESSING order chosen by the library: one workgroup per
+ * image first sorts its proposals by (FPN level, Morton code of the box centre) into order_workspace ([N * per_image] int32,
+ * per_image <= 2048, else the order is left as given), and the ROIAlign workgroups walk that order, one contiguous stretch per
+ * XCD.  Outputs land where pe_roi_align_nhwc puts them, bit for bit; only the feature traffic changes (proposals arrive in RPN
+ * score order, scattered over the pyramid).  This is what ROIPooler's per-level nonzero/index_put grouping
+ * (modeling/poolers.py:219-233) does for locality in the reference, without its four device synchronisations. */
+int pe_roi_align_nhwc_sorted(const void* const* feats_host, const int32_t* feat_hw_host, const float* scales_host,
+                             int32_t num_levels, int32_t N, int32_t C, int32_t dtype, const float* boxes, int32_t per_image,
+                             const int32_t* counts, int32_t pooled_h, int32_t pooled_w, int32_t sampling_ratio,
+                             int32_t aligned, void* output, int32_t* out_level, int32_t* order_workspace, void* stream);
+
 /* ROIAlign backward (training half).  Replaces roi_align_backward of detectron2._C
  * (layers/csrc/ROIAlign/ROIAlign.h:86-115, ROIAlign_cuda.cu:141-306,369-420; same arithmetic as ROIAlign_cpu.cpp:221-394)
  * behind _ROIAlign.backward (layers/roi_align.py:26-42) and, with num_levels == 4, the backward of ROIPooler's per-level

@@ -72,9 +72,14 @@ def nms(boxes, scores, iou_threshold):
 # ------------------------------------------------------------------------------------------------
 # ROIAlign
 # ------------------------------------------------------------------------------------------------
+ROI_SORT = True    # A/B switch of bench.py --roi-sort (results are identical either way)
+
+
 def roi_align_nhwc(feats, rois, *, scales, pooled, sampling_ratio=0, aligned=True, counts=None, per_image=0,
-                   num_rois=None, out=None, want_levels=False):
-    """feats: list (1 or 4) of NHWC tensors (fp16 or fp32, same dtype/C); rois: [R,5] or boxes [N,per_image,4]."""
+                   num_rois=None, out=None, want_levels=False, sort=None):
+    """feats: list (1 or 4) of NHWC tensors (fp16 or fp32, same dtype/C); rois: [R,5] or boxes [N,per_image,4].
+    sort (boxes form only): the workgroups take the ROIs in (level, Morton cell) order, one contiguous stretch per XCD
+    (pe_roi_align_nhwc_sorted) - the same results at the same places, fewer feature bytes fetched."""
     f0 = feats[0]
     _lib.require_cuda(f0, rois)
     N, C = f0.shape[0], f0.shape[3]
@@ -88,6 +93,13 @@ def roi_align_nhwc(feats, rois, *, scales, pooled, sampling_ratio=0, aligned=Tru
     ptrs = (ctypes.c_void_p * nl)(*[f.data_ptr() for f in feats])
     hw = (ctypes.c_int32 * (2 * nl))(*sum([[f.shape[1], f.shape[2]] for f in feats], []))
     sc = (ctypes.c_float * nl)(*scales)
+    if (ROI_SORT if sort is None else sort) and not have_b and per_image > 0 and R == N * per_image:
+        order = torch.empty((R,), dtype=torch.int32, device=f0.device)
+        st = _lib.lib().pe_roi_align_nhwc_sorted(ptrs, hw, sc, nl, N, C, dtype, _lib.ptr(rois.contiguous()), int(per_image),
+                                                 _lib.ptr(counts), pooled[0], pooled[1], int(sampling_ratio), int(bool(aligned)),
+                                                 _lib.ptr(out), _lib.ptr(lv), _lib.ptr(order), _lib.stream())
+        _lib.check(st, "pe_roi_align_nhwc_sorted")
+        return (out, lv) if want_levels else out
     st = _lib.lib().pe_roi_align_nhwc(ptrs, hw, sc, nl, N, C, dtype, _lib.ptr(rois.contiguous()), int(have_b), R,
                                       int(per_image), _lib.ptr(counts), pooled[0], pooled[1], int(sampling_ratio),
                                       int(bool(aligned)), _lib.ptr(out), _lib.ptr(lv), _lib.stream())

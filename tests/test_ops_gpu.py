@@ -697,6 +697,26 @@ def test_roi_align_fp16_and_dead_rows(L):
     assert float(got[41:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("N,P", [(3, 1000), (2, 37), (1, 2048), (2, 2100)])
+def test_roi_align_sorted_order_moves_no_result(L, N, P):
+    """pe_roi_align_nhwc_sorted (level / Morton processing order, XCD-contiguous) against pe_roi_align_nhwc: the same bits at
+    the same places, the same levels, dead rows zero; per_image > 2048 falls back to the given order."""
+    g = torch.Generator().manual_seed(N * 7919 + P)
+    feats = [torch.randn(N, 200 >> l, 256 >> l, 64, generator=g).half().cuda() for l in range(4)]
+    ctr = torch.rand(N, P, 2, generator=g) * torch.tensor([1000.0, 780.0])
+    wh = torch.exp(torch.rand(N, P, 2, generator=g) * 5.5 + 1.5)            # 4 .. 1100 px: every level
+    boxes = torch.cat([ctr - wh / 2, ctr + wh / 2], dim=2).cuda()
+    counts = torch.tensor([P, P // 3, 0][:N] if N > 1 else [P - 5], dtype=torch.int32).cuda()
+    kw = dict(scales=[1 / 4, 1 / 8, 1 / 16, 1 / 32], pooled=(7, 7), counts=counts, per_image=P, want_levels=True)
+    a, la = L.roi_align_nhwc(feats, boxes, sort=False, **kw)
+    b, lb = L.roi_align_nhwc(feats, boxes, sort=True, **kw)
+    assert torch.equal(la, lb) and set(la.unique().tolist()) >= {0, 1, 2, 3}
+    assert torch.equal(a, b)
+    assert float(a.view(N, P, -1)[0, :counts[0]].abs().sum()) > 0
+    if N > 1:
+        assert float(a.view(N, P, -1)[1, counts[1]:].abs().sum()) == 0
+
+
 def test_roi_align_backward_matches_oracle_and_autograd(L):
     """Training half: the backward kernel == the oracle's restatement of ROIAlign_cpu.cpp:221-394 (atomics:
     tolerance, not bits), rows beyond counts contribute nothing, and `layers.ROIAlign` is differentiable end to end."""
