@@ -68,6 +68,7 @@ def parse(argv=None):
     ap.add_argument("--serial-detectors", action="store_true", help="run the detectors back to back on one stream")
     ap.add_argument("--wd9-tail-wgs", type=int, default=0, help="A/B: workgroups of the persistent fused-tail kernel (0 = the library's default)")
     ap.add_argument("--wd9-wgs", type=int, default=0, help="A/B: workgroups of the persistent pure 3x3 kernel (0 = the library's default)")
+    ap.add_argument("--no-power", action="store_true", help="do not poll rocm-smi for board power during the timed region")
     ap.add_argument("--roi-sort", type=int, default=1, help="0: ROIAlign takes the proposals in RPN order (A/B; identical results)")
     ap.add_argument("--wd9-mode", type=int, default=-1,
                     help="A/B (csrc/test_hooks.h): 0 = two-wave weights-direct kernels only (csrc/conv_wd.h), 1 = persistent one-wave-per-SIMD "
@@ -309,6 +310,53 @@ def proben_micro(device, B=4096, reps=20):
             "note": "one wavefront per image, float64; latency / LDS bound, not HBM bound (the whole batch is " + str(round(nbytes / 1e6, 1)) + " MB)"}
 
 
+class BoardPower:
+    """rocm-smi polled from a thread while the timed region runs (rank 0's device): board power and shader clock.  The hot kernels of
+    this path run AT the board's power cap (profiles/r04_power_kernels.txt): the cap, not the nominal MFMA peak, is
+    what bounds them, so the line reports it.  Best effort: no rocm-smi -> {"available": false}."""
+
+    def __init__(self, device_index):
+        import threading
+        self.dev, self.rows, self.stop, self.cap = str(device_index), [], False, None
+        self.thread = threading.Thread(target=self._run, daemon=True)
+
+    def _smi(self, *flags):
+        import re
+        import subprocess
+        out = subprocess.run(["rocm-smi", "-d", self.dev, *flags, "--json"], capture_output=True, text=True, timeout=10).stdout
+        card = next(v for v in json.loads(out[out.index("{"):]).values() if isinstance(v, dict))
+        return {k: float(re.search(r"[-+]?\d+(\.\d+)?", str(v)).group(0)) for k, v in card.items() if re.search(r"\d", str(v))}
+
+    def _run(self):
+        while not self.stop:
+            try:
+                c = self._smi("--showpower", "--showclocks")
+                self.rows.append((time.perf_counter(), next(v for k, v in c.items() if "Power" in k), c.get("sclk clock speed:")))
+                time.sleep(0.05)
+            except Exception:
+                time.sleep(0.2)
+
+    def start(self):
+        try:
+            self.cap = next(v for k, v in self._smi("--showmaxpower").items() if "Power" in k)
+        except Exception:
+            self.cap = None
+        self.thread.start()
+
+    def result(self, t0, t1, units):
+        self.stop = True
+        rows = [r for r in self.rows if t0 <= r[0] <= t1]
+        if not rows:
+            return {"available": False, "cap_w": self.cap}
+        med = lambda v: sorted(v)[len(v) // 2]
+        w = med([r[1] for r in rows])
+        clk = [r[2] for r in rows if r[2] is not None]
+        return {"available": True, "board_w_median": w, "board_w_max": max(r[1] for r in rows), "cap_w": self.cap,
+                "sclk_mhz_median": med(clk) if clk else None, "samples": len(rows),
+                "joules_per_unit": round(w * (t1 - t0) / units, 3),
+                "source": "rocm-smi --showpower --showclocks polled during the timed region (socket package power)"}
+
+
 def cpu_baseline(sds, cfg, depth, pairs, threads):
     """The oracle = this repo's restatement of the reference's CPU path (torch fp32 NCHW unfused conv/BN/ReLU,
     all-anchor decode, per-level sort, per-level ROIAlign, NumPy-f64 ProbEn), timed on the host cores: all `threads`
@@ -401,12 +449,16 @@ def main(argv=None):
 
     for _ in range(args.warmup):
         out = step()
+    power = BoardPower(local) if rank == 0 and not args.no_power else None
+    if power is not None:
+        power.start()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
     fence()
-    dt = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    dt = t1 - t0
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -441,6 +493,8 @@ def main(argv=None):
                                               + ("ON (--wd9-mode)" if args.wd9_mode >= 0 and args.wd9_mode & 4 else
                                                  "opt-in and OFF here: faster as a launch of its own, slower in every pipeline (DESIGN.md 10.4)"))},
         }
+        if power is not None:
+            line["power"] = power.result(t0, t1, B * args.steps)    # rank 0's board, rank 0's units
         if world > 1 or comm_active():
             line["config"]["collective"] = "one all_gather_into_tensor of the fused rows per step (RCCL)" + ("" if world > 1 else
                                            "; PROBEN_FORCE_DIST: a ONE-rank RCCL group, the collective runs but moves nothing between devices")
