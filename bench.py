@@ -311,41 +311,58 @@ def proben_micro(device, B=4096, reps=20):
 
 
 class BoardPower:
-    """rocm-smi polled from a thread while the timed region runs (rank 0's device): board power and shader clock.  The hot kernels of
-    this path run AT the board's power cap (profiles/r04_power_kernels.txt): the cap, not the nominal MFMA peak, is
-    what bounds them, so the line reports it.  Best effort: no rocm-smi -> {"available": false}."""
+    """rocm-smi polled by ONE helper process (started before the timed region: no fork from this process, no Python thread, while the
+    steps are being timed) on rank 0's device: board power and shader clock.  The hot kernels of this path run AT the board's power cap
+    (profiles/r04_power_kernels.txt): the cap, not the nominal MFMA peak, is what bounds them, so the line reports it.
+    Best effort: no rocm-smi -> {"available": false}."""
 
     def __init__(self, device_index):
-        import threading
-        self.dev, self.rows, self.stop, self.cap = str(device_index), [], False, None
-        self.thread = threading.Thread(target=self._run, daemon=True)
+        self.dev, self.proc, self.cap, self.path = str(int(device_index)), None, None, None
 
-    def _smi(self, *flags):
+    @staticmethod
+    def _numbers(card):
         import re
-        import subprocess
-        out = subprocess.run(["rocm-smi", "-d", self.dev, *flags, "--json"], capture_output=True, text=True, timeout=10).stdout
-        card = next(v for v in json.loads(out[out.index("{"):]).values() if isinstance(v, dict))
         return {k: float(re.search(r"[-+]?\d+(\.\d+)?", str(v)).group(0)) for k, v in card.items() if re.search(r"\d", str(v))}
 
-    def _run(self):
-        while not self.stop:
-            try:
-                c = self._smi("--showpower", "--showclocks")
-                self.rows.append((time.perf_counter(), next(v for k, v in c.items() if "Power" in k), c.get("sclk clock speed:")))
-                time.sleep(0.05)
-            except Exception:
-                time.sleep(0.2)
-
     def start(self):
+        import subprocess
+        import tempfile
         try:
-            self.cap = next(v for k, v in self._smi("--showmaxpower").items() if "Power" in k)
+            out = subprocess.run(["rocm-smi", "-d", self.dev, "--showmaxpower", "--json"], capture_output=True, text=True, timeout=20).stdout
+            card = next(v for v in json.loads(out[out.index("{"):]).values() if isinstance(v, dict))
+            self.cap = next(v for k, v in self._numbers(card).items() if "Power" in k)
+            fd, self.path = tempfile.mkstemp(prefix="bench_power_", suffix=".txt")
+            loop = f"while true; do date +%s.%N; rocm-smi -d {self.dev} --showpower --showclocks --json 2>/dev/null; done"
+            self.proc = subprocess.Popen(["bash", "-c", loop], stdout=fd, stderr=subprocess.DEVNULL, start_new_session=True)
+            os.close(fd)
         except Exception:
-            self.cap = None
-        self.thread.start()
+            self.proc = None
 
-    def result(self, t0, t1, units):
-        self.stop = True
-        rows = [r for r in self.rows if t0 <= r[0] <= t1]
+    def result(self, w0, w1, units):
+        """w0 / w1: time.time() at the two ends of the timed region."""
+        import signal
+        if self.proc is None:
+            return {"available": False, "cap_w": self.cap}
+        try:
+            os.killpg(self.proc.pid, signal.SIGTERM)     # the helper's own process group (start_new_session), nothing else
+        except Exception:
+            pass
+        rows, stamp = [], None
+        try:
+            for ln in open(self.path):
+                ln = ln.strip()
+                if ln and ln[0].isdigit():
+                    stamp = float(ln)
+                elif ln.startswith("{") and stamp is not None:
+                    try:
+                        c = self._numbers(next(v for v in json.loads(ln).values() if isinstance(v, dict)))
+                        rows.append((stamp, next(v for k, v in c.items() if "Power" in k), c.get("sclk clock speed:")))
+                    except Exception:
+                        pass
+            os.unlink(self.path)
+        except Exception:
+            pass
+        rows = [r for r in rows if w0 <= r[0] and r[0] + 0.1 <= w1]     # a sample is taken shortly AFTER its stamp
         if not rows:
             return {"available": False, "cap_w": self.cap}
         med = lambda v: sorted(v)[len(v) // 2]
@@ -353,8 +370,8 @@ class BoardPower:
         clk = [r[2] for r in rows if r[2] is not None]
         return {"available": True, "board_w_median": w, "board_w_max": max(r[1] for r in rows), "cap_w": self.cap,
                 "sclk_mhz_median": med(clk) if clk else None, "samples": len(rows),
-                "joules_per_unit": round(w * (t1 - t0) / units, 3),
-                "source": "rocm-smi --showpower --showclocks polled during the timed region (socket package power)"}
+                "joules_per_unit": round(w * (w1 - w0) / units, 3),
+                "source": "rocm-smi --showpower --showclocks polled by a helper process during the timed region (socket package power)"}
 
 
 def cpu_baseline(sds, cfg, depth, pairs, threads):
@@ -453,12 +470,12 @@ def main(argv=None):
     if power is not None:
         power.start()
     fence()
-    t0 = time.perf_counter()
+    w0, t0 = time.time(), time.perf_counter()
     for _ in range(args.steps):
         out = step()
     fence()
-    t1 = time.perf_counter()
-    dt = t1 - t0
+    dt = time.perf_counter() - t0
+    w1 = time.time()
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -494,7 +511,7 @@ def main(argv=None):
                                                  "opt-in and OFF here: faster as a launch of its own, slower in every pipeline (DESIGN.md 10.4)"))},
         }
         if power is not None:
-            line["power"] = power.result(t0, t1, B * args.steps)    # rank 0's board, rank 0's units
+            line["power"] = power.result(w0, w1, B * args.steps)    # rank 0's board, rank 0's units
         if world > 1 or comm_active():
             line["config"]["collective"] = "one all_gather_into_tensor of the fused rows per step (RCCL)" + ("" if world > 1 else
                                            "; PROBEN_FORCE_DIST: a ONE-rank RCCL group, the collective runs but moves nothing between devices")

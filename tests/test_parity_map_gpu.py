@@ -7,10 +7,11 @@ detector are scored against the SAME ground truth with the same COCO evaluator (
 csrc/cocoeval.cpp) and the AP tables are compared.  The measurement itself lives in tests/parity_map.py; scripts/map_parity.py
 writes its record for profiles/ (this file only asserts).
 
-What the numbers mean (profiles/r04_map_parity.json, profiles/r04_map_fp16_ablation.json): the delta is the price of
-fp16 activations - the ORACLE with fp16 rounding emulated at the device's storage points reproduces it (AP50 +0.32 vs the device's
-+0.28 on the fixture set) - and it is a few tenths of a point, i.e. OUTSIDE north_star's 0.1: test_map_within_north_star_tolerance
-reports that as an expected failure instead of hiding it behind a wider bound."""
+What the numbers mean (profiles/r04_map_parity.json, profiles/r04_map_fp16_ablation.json): on ONE 256-frame set the AP
+figures of the two detectors differ by a few tenths of a point with either sign - the ORACLE with fp16 rounding emulated at the device's
+storage points scatters the same way (+0.22 / +0.32 / +0.31 on the fixture set) - and over five disjoint sets (1 280 frames, 7 585
+objects) the differences average out: mean dAP -0.04 (std over sets 0.19), dAP50 -0.07 (0.29), dAP75 -0.01 (0.27).  north_star's 0.1
+point holds for the mean, not for a single 256-frame set; the tests below assert exactly that."""
 import os
 
 import numpy as np
@@ -31,10 +32,10 @@ def record(golden_dir):
 
 
 def test_map_of_hip_and_oracle_against_the_same_ground_truth(golden_dir):
-    """Regression bound: every AP figure of every evaluation set within 1.0 point of the oracle's, the mean over the sets within
-    0.6 (APm, a few hundred medium objects per set: 1.0), the detection count within 1 %, and no systematic box shift (signed mean
-    offset of the matched pairs < 0.1 px).  Measured: profiles/r04_map_parity.json - the deltas change sign with the rounding
-    realisation (r03 kernels: AP75 +0.25, r04 kernels: -0.44 on the same set), as noise does and a bias does not."""
+    """Regression bound: every AP figure of every evaluation set within 1.0 point of the oracle's (measured: at most 0.59), the mean
+    over the sets within 0.3 (measured: at most 0.08), the detection count within 1 %, and no systematic box shift (signed mean
+    offset of the matched pairs < 0.1 px).  Measured: profiles/r04_map_parity.json - the deltas change sign from set to set and
+    with the rounding realisation (r03 / r04 kernels on the same set), as noise does and a bias does not."""
     rec = record(golden_dir)
     z, _, _, gts = load_fixture(golden_dir)
     first = next(iter(rec["sets"].values()))
@@ -45,15 +46,19 @@ def test_map_of_hip_and_oracle_against_the_same_ground_truth(golden_dir):
             assert abs(s["delta"][n]) <= 1.0, (name, n, s["delta"])
         assert abs(s["hip_detections"] - s["oracle_detections"]) <= 0.01 * s["oracle_detections"], name
     for n in ("AP", "AP50", "AP75", "APm", "APl"):
-        assert abs(rec["delta_mean"][n]) <= (1.0 if n == "APm" else 0.6), (n, rec["delta_mean"])
+        assert abs(rec["delta_mean"][n]) <= 0.3, (n, rec["delta_mean"])
     off = rec["matched_pairs_signed"]["box_offset_mean_px"]
-    assert max(abs(v) for v in off.values()) < 0.1, off      # measured +0.045 px on x1 (13 sigma), +0.03 on y1 - and the oracle with fp16 rounding emulated shows the same +0.042 / +0.024: an fp16 effect, not a kernel one
+    assert max(abs(v) for v in off.values()) < 0.1, off      # measured +0.048 px on x1 (30 sigma over 28 605 pairs), +0.026 on y1 - and the oracle with fp16 rounding emulated shows the same +0.042 / +0.024: an fp16 effect, not a kernel one
 
 
-@pytest.mark.xfail(strict=False, reason="fp16 activations: measured +0.2 .. +0.4 point on AP / AP50 (profiles/r04_map_parity.json); north_star asks 0.1")
 def test_map_within_north_star_tolerance(golden_dir):
+    """north_star: mAP within 1e-3 (0.1 point) of the reference's.  Asserted on the MEAN over the five evaluation sets (1 280 frames):
+    measured dAP -0.04, dAP50 -0.07, dAP75 -0.01 with a standard error of 0.09-0.13 - consistent with zero, inside the tolerance.  A
+    single 256-frame set cannot resolve 0.1 point (std over sets 0.19-0.29): that is the sets' granularity, not the detector's."""
     rec = record(golden_dir)
-    assert abs(rec["delta_mean"]["AP50"]) <= NORTH_STAR_POINTS and abs(rec["delta_mean"]["AP"]) <= NORTH_STAR_POINTS, rec["delta_mean"]
+    assert rec["n_sets"] >= 5, "the multi-set fixture (tests/golden/pseudo_heads_r101_sets.npz) is missing"
+    for n in ("AP", "AP50", "AP75"):
+        assert abs(rec["delta_mean"][n]) <= NORTH_STAR_POINTS, (n, rec["delta_mean"], rec["delta_std"])
 
 
 def test_committed_oracle_rows_are_what_the_oracle_computes_here(golden_dir):
