@@ -4,6 +4,7 @@
 namespace pe {
 int wd9_conv3x3(ConvWdArgs a, hipStream_t st);   // csrc/conv_wd9.hip: the large launches of the same layers, same bits
 int wd9_bottleneck_tail(ConvWdArgs a, hipStream_t st);   // csrc/conv_wd9.hip: res4 geometry (image width 64), chosen by geometry only
+int wd9_rpn_head(ConvWdArgs a, hipStream_t st);   // csrc/conv_wd9.hip: the fused RPN head on the one-wave structure, same bits
 }
 
 namespace {
@@ -86,7 +87,8 @@ extern "C" int pe_conv3x3_wd_rpn_head_f16(const void* input, const void* packed_
     a.in = (const _Float16*)input; a.wpk = (const _Float16*)packed_weight; a.bias = bias; a.out = nullptr;
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = 256; a.M = (int)M; a.relu = 1; a.out_stride = 256;
     a.head_w = (const _Float16*)packed_head; a.head_b = head_bias16; a.head_out = head_out;
-    const int st = wd::launch_conv3x3_wd<1, 4, 4, 4, 0, 1>(a, (hipStream_t)stream);
+    int st = pe::wd9_rpn_head(a, (hipStream_t)stream);
+    if (st == PE_ERR_UNSUPPORTED) st = wd::launch_conv3x3_wd<1, 4, 4, 4, 0, 1>(a, (hipStream_t)stream);
     if (st != PE_OK) {
         pe::set_error("pe_conv3x3_wd_rpn_head_f16: unsupported geometry");
         return st;

@@ -73,6 +73,21 @@ __device__ __forceinline__ void acc_read8(float (&x)[8]) {
         : "n"(LO), "n"(LO + 1), "n"(LO + 2), "n"(LO + 3), "n"(LO + 4), "n"(LO + 5), "n"(LO + 6), "n"(LO + 7));
 }
 
+// an MFMA whose accumulator is 16 VGPRs, spelled out (a compiler-placed MFMA could land in the accumulation file, which belongs to the
+// statements above), and the wait states between the last MFMA of such a chain and the first VALU / DS read of its result
+__device__ __forceinline__ void mfma_vgpr(float16v& c, half8 w, half8 p) {
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(w), "v"(p));
+}
+// first MFMA of such a chain: C = 0 (no VALU-initialised accumulator: a VALU write right in front of an MFMA that reads the register
+// as SrcC is a hazard the compiler cannot see here - measured: the last v_mov of a zero-init arrived too late), and two wait states
+// for operand registers a VALU instruction may have written just before
+__device__ __forceinline__ void mfma_vgpr_zero(float16v& c, half8 w, half8 p) {
+    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(c) : "v"(w), "v"(p));
+}
+__device__ __forceinline__ void mfma_vgpr_settle(float16v& c, half8 p0, half8 p1, half8 p2, half8 p3) {
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" : "+v"(c) : "v"(p0), "v"(p1), "v"(p2), "v"(p3));
+}
+
 // one LDS-DMA piece: 64 lanes x 16 B, lane-linear at LDS byte address `lds` (wave-uniform); `voff` = per-lane byte offset into the
 // buffer or an out-of-range value (-> zeros).  M0 is compiler-reserved: saved and restored inside the statement.
 __device__ __forceinline__ void dma16(unsigned voff, unsigned lds, int4v rsrc) {
@@ -113,15 +128,19 @@ __device__ __forceinline__ void static_for(F&& f) {      // f(ic<0>{}), ..., f(i
 
 // VAR = SM + 4 * EP.  SM, how the slab reaches LDS: 0 = LDS-DMA issued behind the K-step's fragment reads, 1 = LDS-DMA late in the
 //   K-step (behind accumulator block (1, 4), when the fragment reads have returned), 2 = register-staged (buffer_load a group ahead,
-//   ds_write_b128 in the next group).  EP, the epilogue's stores: 0 = straight from the accumulator layout (a lane owns 64 B of a
-//   pixel: four 16-byte pieces), 1 = through a wave-private LDS patch as whole 128-byte lines.
+//   ds_write_b128 in the next group).  EP, the epilogue: 0 = stores straight from the accumulator layout (a lane owns 64 B of a
+//   pixel: four 16-byte pieces), 1 = through a wave-private LDS patch as whole 128-byte lines, 2 = the fused RPN HEAD of
+//   conv_wd.h's HEAD == 1 (t = relu(conv + bias) never leaves the registers: the accumulator layout IS the MFMA B-fragment layout
+//   of a pre-permuted head weight, pe_conv_wd_pack_head; 16 fp32 outputs per pixel, cross-wave sum through 32 KiB of LDS in the
+//   two-wave kernel's order - same bits).
 // ABL (measurement builds, results wrong): 1 = no output stores, 2 = no slab traffic, 4 = no weight loads in the loop
 // DBG: wave 0 of every workgroup writes s_memtime stamps (kernel start, and per tile: loop start, loop end, epilogue end)
 template <int SEGL, int TPX, int DEPTH, int RELU, int VAR = 0, int ABL = 0, int DBG = 0>
 __global__ __launch_bounds__(THREADS, 1) void conv3x3_wd9_kernel(pe::ConvWdArgs a, unsigned long long* dbg) {
     using G_ = Geo<SEGL, TPX>;
     constexpr int SEG = G_::SEG, BPX = G_::BPX, SEGP = G_::SEGP, SLAB = G_::SLAB, NPIECE = G_::NPIECE, PPW = G_::PPW, NSEG = G_::NSEG;
-    constexpr int SM = VAR & 3, EP = (VAR >> 2) & 1;
+    constexpr int SM = VAR & 3, EP = (VAR >> 2) & 3;
+    static_assert(EP != 2 || TPX == 8, "fused head: two halves of four pixel blocks");
     static_assert(12 % DEPTH == 0, "weight prefetch depth must divide the 12 K-steps of a group");
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     typedef __attribute__((address_space(3))) unsigned char lds_byte;
@@ -254,6 +273,11 @@ __global__ __launch_bounds__(THREADS, 1) void conv3x3_wd9_kernel(pe::ConvWdArgs 
         }
     }
     load_bias(t_first);
+    half8 hw[EP == 2 ? 4 : 1];      // fused head: K-step j covers accumulator registers (blk j >> 1, half j & 1) of this wave's 64 channels
+    if constexpr (EP == 2) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) hw[j] = *reinterpret_cast<const half8*>(a.head_w + ((wn * 4 + j) * 64 + lane) * 8);
+    }
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) {
         w_load1(d, 0, w_cur + d * (WN * 2048));
@@ -341,7 +365,55 @@ __global__ __launch_bounds__(THREADS, 1) void conv3x3_wd9_kernel(pe::ConvWdArgs 
             const int m0 = tile_m0(tile), n0 = (tile % a.tiles_n) * (WN * 64);
             const unsigned ob = (unsigned)(((m0 + (lane & 31)) * a.out_stride + n0 + wn * 64 + (lane >> 5) * 32) * 2);
             asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7");      // the last MFMAs' results must have reached the register file
-            if constexpr (EP == 0) {
+            if constexpr (EP == 2) {
+                float* red = reinterpret_cast<float*>(smem + 3 * SLAB);     // [4 waves][128 px][16] fp32 behind the ring
+                static_for<2>([&](auto hf_) {
+                    constexpr int hf = decltype(hf_)::value;
+                    static_for<4>([&](auto ii_) {
+                        constexpr int i = hf * 4 + decltype(ii_)::value;
+                        float16v hd;
+                        // all four B fragments first, then the four MFMAs back to back, then the wait states: an MFMA reads its
+                        // operand registers for several cycles after it has issued, and nothing tells the compiler (the MFMAs are
+                        // asm statements) not to recycle them at once - the settle statement keeps them alive
+                        half8 bf[4];
+                        static_for<4>([&](auto j_) {
+                            constexpr int j = decltype(j_)::value, blk = j >> 1, hh = j & 1;
+                            float x[8];
+                            acc_read8<(blk * TPX + i) * 16 + hh * 8>(x);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) bf[j][e] = (_Float16)pe::relu_nan(x[e] + bias_v[blk][hh * 8 + e]);
+                        });
+                        mfma_vgpr_zero(hd, hw[0], bf[0]);
+                        mfma_vgpr(hd, hw[1], bf[1]);
+                        mfma_vgpr(hd, hw[2], bf[2]);
+                        mfma_vgpr(hd, hw[3], bf[3]);
+                        mfma_vgpr_settle(hd, bf[0], bf[1], bf[2], bf[3]);
+                        // rows (= head outputs) held by this lane: 4 h + (r & 3) + 8 (r >> 2); rows 16 .. 31 are padding
+                        float* dst = red + ((wn * 128 + (i & 3) * 32 + (lane & 31)) * 16) + (lane >> 5) * 4;
+                        *reinterpret_cast<float4*>(dst) = make_float4(hd[0], hd[1], hd[2], hd[3]);
+                        *reinterpret_cast<float4*>(dst + 8) = make_float4(hd[4], hd[5], hd[6], hd[7]);
+                    });
+                    __syncthreads();
+                    {
+                        const int px = tid >> 1, q = tid & 1;
+                        const int m = m0 + hf * 128 + px;
+                        float4 s0 = *reinterpret_cast<const float4*>(a.head_b + q * 8), s1 = *reinterpret_cast<const float4*>(a.head_b + q * 8 + 4);
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) {
+                            const float4 x0 = *reinterpret_cast<const float4*>(red + (w * 128 + px) * 16 + q * 8);
+                            const float4 x1 = *reinterpret_cast<const float4*>(red + (w * 128 + px) * 16 + q * 8 + 4);
+                            s0.x += x0.x; s0.y += x0.y; s0.z += x0.z; s0.w += x0.w;
+                            s1.x += x1.x; s1.y += x1.y; s1.z += x1.z; s1.w += x1.w;
+                        }
+                        if (m < a.M && !(ABL & 1)) {
+                            float* o = a.head_out + (size_t)m * 16 + q * 8;
+                            *reinterpret_cast<float4*>(o) = s0;
+                            *reinterpret_cast<float4*>(o + 4) = s1;
+                        }
+                    }
+                    __syncthreads();      // `red` is rewritten by the next half / the next tile
+                });
+            } else if constexpr (EP == 0) {
                 static_for<TPX * 4>([&](auto q_) {
                     constexpr int q = decltype(q_)::value, i = q >> 2, blk = (q >> 1) & 1, hh = q & 1;
                     float x[8];
@@ -405,7 +477,8 @@ inline int launch_r(pe::ConvWdArgs a, hipStream_t st, int workgroups, unsigned l
     a.seg = G_::SEG; a.nseg = G_::NSEG;
     a.tiles_m = pe::ceil_div(a.M, G_::BPX);
     a.tiles_n = a.Cout / (WN * 64);
-    const size_t lds = (size_t)3 * G_::SLAB + 16384;
+    constexpr size_t lds = (size_t)3 * G_::SLAB + (((VAR >> 2) & 3) == 2 ? 32768 : 16384);
+    static_assert(lds <= 160 * 1024, "ring + epilogue area must fit the CU's LDS");
     PE_ENSURE_LDS((conv3x3_wd9_kernel<SEGL, TPX, DEPTH, RELU, VAR, ABL, DBG>), lds, "conv3x3_wd9");
     const int ntile = a.tiles_m * a.tiles_n;
     hipLaunchKernelGGL((conv3x3_wd9_kernel<SEGL, TPX, DEPTH, RELU, VAR, ABL, DBG>), dim3(ntile < workgroups ? ntile : workgroups), dim3(THREADS), lds, st, a, dbg);
@@ -425,6 +498,19 @@ inline int launch(pe::ConvWdArgs a, hipStream_t st, int workgroups = 256, unsign
         case 128: if constexpr (TPX % 4 == 0) return launch_t<7, TPX, DEPTH, VAR, ABL, DBG>(a, st, workgroups, dbg); else return PE_ERR_UNSUPPORTED;
         case 64: if constexpr (TPX % 2 == 0) return launch_t<6, TPX, DEPTH, VAR, ABL, DBG>(a, st, workgroups, dbg); else return PE_ERR_UNSUPPORTED;
         case 32: if constexpr (TPX <= 6) return launch_t<5, TPX, DEPTH, VAR, ABL, DBG>(a, st, workgroups, dbg); else return PE_ERR_UNSUPPORTED;
+    }
+    return PE_ERR_UNSUPPORTED;
+}
+
+// fused RPN head (EP = 2): ReLU is part of the head, widths 64 / 128 / 256, one 256-channel tile column
+template <int TPX, int DEPTH, int VAR>
+inline int launch_head(pe::ConvWdArgs a, hipStream_t st, int workgroups = 256) {
+    static_assert(((VAR >> 2) & 3) == 2, "launch_head: VAR must select the head epilogue");
+    if (!geometry_ok(a.H, a.W, TPX) || a.Cout != WN * 64 || !a.head_w || !a.head_b || !a.head_out) return PE_ERR_UNSUPPORTED;
+    switch (a.W) {
+        case 256: return launch_r<8, TPX, DEPTH, 1, VAR>(a, st, workgroups, nullptr);
+        case 128: return launch_r<7, TPX, DEPTH, 1, VAR>(a, st, workgroups, nullptr);
+        case 64: return launch_r<6, TPX, DEPTH, 1, VAR>(a, st, workgroups, nullptr);
     }
     return PE_ERR_UNSUPPORTED;
 }

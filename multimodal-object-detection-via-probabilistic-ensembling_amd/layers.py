@@ -363,7 +363,9 @@ def conv3x3_wd_rpn_head(x, packed, bias, packed_head, head_bias16, out=None):
     _lib.check(st, "pe_conv3x3_wd_rpn_head_f16")
     if PROFILE is not None:
         M = N * H * W
-        PROFILE.append({"variant": "conv3x3_wd_kernel<1, 4, 4, 4, 0, 1>", "shape": f"N{N} {H}x{W} Cin{Cin} Cout256+head k3 s1 res0 f321",
+        wd9 = _lib.test_hooks().pe_test_wd9_head_takes(N, H, W)
+        PROFILE.append({"variant": "conv3x3_wd9_kernel<8, 4, 9, 1>" if wd9 else "conv3x3_wd_kernel<1, 4, 4, 4, 0, 1>",
+                        "shape": f"N{N} {H}x{W} Cin{Cin} Cout256+head k3 s1 res0 f321",
                         "flops": 2.0 * M * 256 * 9 * Cin + 2.0 * M * 15 * 256, "bytes": float(M * Cin * 2 + 256 * 9 * Cin * 2 + M * 15 * 4),
                         "replay": (lambda: conv3x3_wd_rpn_head(x, packed, bias, packed_head, head_bias16, out=out))})
     return out

@@ -204,11 +204,47 @@ def test_conv3x3_wd9_is_bit_identical_to_conv_wd(L, case):
         hooks.pe_test_set_wd9_mode(2)
         new1, new2 = run(), run()
     finally:
-        hooks.pe_test_set_wd9_mode(1)
+        hooks.pe_test_set_wd9_mode(-1)
     torch.cuda.synchronize()
     assert torch.equal(new1, new2)
     assert torch.equal(new1, old)
     torch.testing.assert_close(new1.permute(0, 3, 1, 2).float(), ref, rtol=4e-3, atol=4e-3)
+
+
+@pytest.mark.parametrize("shape", [(2, 40, 64, 256), (1, 13, 128, 256), (2, 9, 256, 256), (1, 5, 256, 64), (3, 3, 64, 128), (33, 2, 128, 256)])
+def test_fused_rpn_head_wd9_is_bit_identical_to_conv_wd(L, shape):
+    """The fused RPN head on the one-wave structure (csrc/conv_wd9.h, EP = 2: t stays in the accumulators, which ARE the head MFMA's
+    B fragments; cross-wave sum through LDS in the two-wave kernel's order) against conv_wd.h's HEAD == 1: the same bits, for every
+    width, ragged last tiles (H not a multiple of the tile's rows), image seams inside tiles, more tiles than workgroups, twice."""
+    from proben_amd import _lib
+    N, H, W, Cin = shape
+    g = torch.Generator(device="cpu").manual_seed(43)
+    x = torch.randn(N, Cin, H, W, generator=g).cuda().half()
+    w3 = (torch.randn(256, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5).cuda().half()
+    b3 = torch.randn(256, generator=g).cuda()
+    wh = (torch.randn(15, 256, 1, 1, generator=g) / 16.0).cuda().half()
+    b16 = torch.zeros(16, device="cuda")
+    b16[:15] = torch.randn(15, generator=g).cuda()
+    pk = L.conv_wd_pack(w3.permute(0, 2, 3, 1).contiguous())
+    ph = L.conv_wd_pack_head(wh.reshape(15, 256).contiguous())
+    hooks = _lib.test_hooks()
+    run = lambda: L.conv3x3_wd_rpn_head(nhwc(x), pk, b3, ph, b16).clone()
+    try:
+        hooks.pe_test_set_wd9_mode(0)
+        old = run()
+        hooks.pe_test_set_wd9_mode(2 | 8)
+        new1, new2 = run(), run()
+        hooks.pe_test_set_wd9_wgs(8, 0)          # 8 workgroups: every workgroup walks many tiles (the persistent loop's ring hand-over)
+        few = run()
+    finally:
+        hooks.pe_test_set_wd9_wgs(256, 0)
+        hooks.pe_test_set_wd9_mode(-1)
+    torch.cuda.synchronize()
+    assert torch.equal(new1, new2) and torch.equal(new1, few)
+    assert torch.equal(new1, old)
+    t_ref = torch.nn.functional.conv2d(x.float(), w3.float(), b3, padding=1).relu()
+    ref = torch.nn.functional.conv2d(t_ref, wh.float(), b16[:15]).permute(0, 2, 3, 1)
+    torch.testing.assert_close(new1[..., :15], ref, rtol=4e-3, atol=4e-3)
 
 
 @pytest.mark.parametrize("shape", [(2, 40, 64, 256), (1, 13, 128, 256), (3, 5, 32, 256), (2, 8, 256, 512)])
@@ -311,7 +347,7 @@ def test_fused_bottleneck_tail_wd9_geometry(L, shape):
     half = L.bottleneck_tail_wd(xs, p2, b2, p3, b3, r, CoutT)
     L.set_concurrent_streams(1)
     assert torch.equal(half, outs[0])
-    _lib.test_hooks().pe_test_set_wd9_mode(1)
+    _lib.test_hooks().pe_test_set_wd9_mode(-1)
 
 
 @pytest.mark.parametrize("shape", [(2, 8, 64, True, True), (1, 7, 70, False, True), (3, 5, 32, False, False), (2, 13, 130, True, False), (1, 50, 64, False, True)])
