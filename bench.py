@@ -505,7 +505,7 @@ def main(argv=None):
                        "input_residency": ("frames resident in HBM before the timed region (no H2D inside it)" if feeder is None else
                                            "frames in pinned host memory; double-buffered H2D upload of every batch INSIDE the timed region"),
                        "timed_seconds": round(dt, 2), "schedule": sched,
-                       "persistent_kernels": ("csrc/conv_wd9.h (pure 3x3, one 512-register workgroup per CU) takes the 256 -> 256 launches of >= 128 tiles; "
+                       "persistent_kernels": ("csrc/conv_wd9.h (pure 3x3 and the fused RPN head, one 512-register workgroup per CU) takes the 256 -> 256 launches of >= 128 tiles; "
                                               "csrc/conv_wd9_tail.h (fused res4 tail on the same structure) is "
                                               + ("ON (--wd9-mode)" if args.wd9_mode >= 0 and args.wd9_mode & 4 else
                                                  "opt-in and OFF here: faster as a launch of its own, slower in every pipeline (DESIGN.md 10.4)"))},
