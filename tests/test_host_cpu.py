@@ -342,3 +342,45 @@ def test_log_average_miss_rate_properties():
     lamr2, mr2, pts2 = evaluation.log_average_miss_rate(gt, dets)
     assert np.all(mr2[pts2 < 1 / 3] == 1.0) and np.allclose(mr2[pts2 >= 1 / 3], 1 / 3)
     assert 1 / 3 < lamr2 < 1.0
+
+
+def test_bench_board_power_sampler_is_best_effort(tmp_path, monkeypatch):
+    """bench.py's `power` object: a helper process polls rocm-smi during the timed region.  With a rocm-smi that answers, samples
+    inside the window are summarised (median board power, cap, shader clock, joules per unit) and the helper's process group is
+    gone afterwards; without rocm-smi the bench line only says so - the measurement never depends on it."""
+    import importlib.util
+    import stat
+    import subprocess
+    import time
+    spec = importlib.util.spec_from_file_location("bench_for_power_test", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    fake = tmp_path / "rocm-smi"
+    fake.write_text('#!/bin/bash\nif [[ "$*" == *showmaxpower* ]]; then echo \'{"card0": {"Max Graphics Package Power (W)": "1400.0"}}\'; '
+                    'else echo "WARNING: not json"; echo \'{"card0": {"Current Socket Graphics Package Power (W)": "1377.0", '
+                    '"sclk clock speed:": "(1916Mhz)", "sclk clock level:": "1"}}\'; sleep 0.05; fi\n')
+    fake.chmod(fake.stat().st_mode | stat.S_IEXEC)
+    monkeypatch.setenv("PATH", str(tmp_path) + os.pathsep + os.environ["PATH"])
+    p = bench.BoardPower(0)
+    p.start()
+    assert p.proc is not None and p.cap == 1400.0
+    time.sleep(0.2)
+    w0 = time.time()
+    time.sleep(0.8)
+    w1 = time.time()
+    r = p.result(w0, w1, units=64)
+    assert r["available"] and r["board_w_median"] == 1377.0 and r["cap_w"] == 1400.0 and r["sclk_mhz_median"] == 1916.0 and r["samples"] >= 2
+    assert abs(r["joules_per_unit"] - 1377.0 * (w1 - w0) / 64) < 1e-2
+    p.proc.wait(timeout=5)                               # the helper loop (its own session) was terminated
+    for _ in range(40):                                  # grandchildren (the fake tool's `sleep`) die with the group, a moment later
+        if subprocess.run(["pgrep", "-g", str(p.proc.pid)], capture_output=True).returncode != 0:
+            break
+        time.sleep(0.05)
+    else:
+        raise AssertionError("the power helper's process group is still alive")
+    assert not os.path.exists(p.path)
+    # no rocm-smi at all
+    monkeypatch.setenv("PATH", str(tmp_path / "empty"))
+    q = bench.BoardPower(0)
+    q.start()
+    assert q.proc is None and q.result(w0, w1, 1) == {"available": False, "cap_w": None}
