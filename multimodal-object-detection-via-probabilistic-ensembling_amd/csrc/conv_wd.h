@@ -61,6 +61,7 @@ struct ConvWdArgs {
 namespace wd {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef unsigned uint4v __attribute__((ext_vector_type(4)));
 typedef float float16v __attribute__((ext_vector_type(16)));
 
 constexpr int SLAB_ROW_B = 144;  // 128 B of channels + 16 B pad: rows r .. r+15 hit 16 distinct 4-bank groups
@@ -362,6 +363,7 @@ __global__ __launch_bounds__(64 * WM * WN, (TPX <= 4 ? 2 : 1)) void conv3x3_wd_k
         for (int i = 0; i < TPX; ++i) pf[0][i] = *reinterpret_cast<const half8*>(smem + tb[i]);
         const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.tail_res ? a.tail_res : a.in), 0,
                                                                             a.tail_res ? a.M * a.tail_cout * 2 : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rto = __builtin_amdgcn_make_buffer_rsrc(a.tail_out, 0, a.M * a.tail_cout * 2, 0x00020000);
         unsigned rbase[TPX];                              // byte offset of this lane's 64 residual bytes for chunk 0, or out of range
 #pragma unroll
         for (int i = 0; i < TPX; ++i) {
@@ -433,22 +435,46 @@ __global__ __launch_bounds__(64 * WM * WN, (TPX <= 4 ? 2 : 1)) void conv3x3_wd_k
                         for (int e = 0; e < 8; ++e) acc[q >> 1][i][(q & 1) * 8 + e] += (float)rv[q & 1][i][e];
                 }
             }
-            // chunk epilogue: ReLU, fp16, 64 contiguous bytes per lane and pixel block
+            // chunk epilogue: ReLU, fp16.  A lane owns 64 B of a pixel's 128-byte line (this wave's 64 outputs of the chunk); stored
+            // straight from that layout every instruction scatters 16-byte pieces over 64 lines (r02 / r03).  Now half a pixel block
+            // (16 lines) at a time goes through a wave-private 2 KiB LDS patch (piece p of row px in slot p ^ (px & 7)) and leaves
+            // as WHOLE lines, 8 per instruction, with the non-temporal hint: the 210 MB of output streaming through the L2 were what
+            // evicted the shortcut lines between their four quarter reads (the 1.36 x traffic of r03), and whole lines can carry
+            // `nt` without the write amplification partial ones get (`nt` on the 16-byte pieces: 2.7 x the write traffic).
+            // profiles/r04_tail_store_ab.txt: 0.2374 -> 0.2034 ms per launch, 904 -> 931 pairs/s.
+            unsigned char* patch = smem + 128 * TROW + wn * 2048;
+            const int px = lane & 31, hq = lane >> 5;
+            const int rrow = lane >> 3, rc = (lane & 7) ^ (rrow & 7);
+            const unsigned lb = (unsigned)((wn * (NCH * 64) + c * 64 + rc * 8) * 2);
 #pragma unroll
-            for (int i = 0; i < TPX; ++i) {
-                const int m = m0 + i * 32 + (lane & 31);
-                if (m >= a.M) continue;
-                _Float16* o = a.tail_out + (size_t)m * a.tail_cout + ob;
+            for (int i = 0; i < TPX; ++i)
 #pragma unroll
-                for (int blk = 0; blk < 2; ++blk)
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    if ((px >> 4) == h2) {
 #pragma unroll
-                    for (int hh = 0; hh < 2; ++hh) {
-                        half8 v;
+                        for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = (_Float16)pe::relu_nan(acc[blk][i][hh * 8 + e]);
-                        *reinterpret_cast<half8*>(o + blk * 16 + hh * 8) = v;
+                            for (int hh = 0; hh < 2; ++hh) {
+                                half8 v;
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) v[e] = (_Float16)pe::relu_nan(acc[blk][i][hh * 8 + e]);
+                                *reinterpret_cast<half8*>(patch + (px & 15) * 128 + (((hq * 4 + blk * 2 + hh) ^ (px & 7)) * 16)) = v;
+                            }
                     }
-            }
+                    // Half the lanes wrote, all lanes read what OTHER lanes wrote: without a convergent operation in between the
+                    // compiler may (and did) give the non-writing lanes their own copy of the reads on the other side of the
+                    // divergent branch, which the hardware can run BEFORE the writers' side.  LDS itself is in order per wave.
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) {
+                        const half8 v = *reinterpret_cast<const half8*>(patch + r * 1024 + lane * 16);
+                        const int m = m0 + i * 32 + h2 * 16 + r * 8 + rrow;      // rows >= M: beyond the buffer's records, dropped
+                        const unsigned off = (unsigned)m * (unsigned)(a.tail_cout * 2) + lb;
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4v, v), rto, off, 0, 2);      // aux 2 = nt
+                    }
+                    __builtin_amdgcn_wave_barrier();      // the next half's writers overwrite rows the other lanes have just read
+                }
         }
         return;
     }
@@ -544,7 +570,7 @@ int launch_conv3x3_wd(pe::ConvWdArgs a, hipStream_t st) {
     a.tiles_n = a.Cout / (WN * 64);
     size_t lds = (size_t)3 * a.nseg * (a.seg + 2) * SLAB_ROW_B + (size_t)64 * WM * WN * 16;
     if (HEAD == 1 && lds < 32768) lds = 32768;        // the partial head sums reuse the slab ring
-    if (HEAD == 2 && lds < 128 * 528) lds = 128 * 528;  // so does the fp16 copy of t
+    if (HEAD == 2 && lds < 128 * 528 + 4 * 2048) lds = 128 * 528 + 4 * 2048;  // so does the fp16 copy of t; + the line-store patches
     PE_ENSURE_LDS((conv3x3_wd_kernel<WM, WN, TPX, DEPTH, ABL, HEAD>), lds, "conv3x3_wd");
     hipLaunchKernelGGL((conv3x3_wd_kernel<WM, WN, TPX, DEPTH, ABL, HEAD>), dim3(a.tiles_m * a.tiles_n), dim3(64 * WM * WN), lds, st, a);
     return PE_OK;
