@@ -275,6 +275,10 @@ def roofline_leg(step, layers_path="", reps=10):
     k1 = max((k for k in agg if k.startswith("conv_igemm2_kernel<128, 128")), key=lambda k: agg[k][2], default=None)
     if k1 is not None and k1 != dom:
         out["conv1x1"] = with_traffic(describe(k1))
+    # ... and the fused res4 bottleneck tail (the dominant kernel of rounds 2-3; round 4's line stores put it behind the 1x1 class)
+    kt = max((k for k in agg if k.endswith(", 0, 2>") or k.startswith("conv3x3_wd9_tail")), key=lambda k: agg[k][2], default=None)
+    if kt is not None and kt != dom:
+        out["res4_tail"] = with_traffic(describe(kt))
     out["method"] = ("avg_launch_ms = HIP-event timing of every distinct launch replayed back-to-back on the launch stream; "
                      "agrees with rocprofv3 --kernel-trace --stats of `bench.py --serial-detectors` (profiles/).  In the default "
                      "two-stream run co-running kernels stretch each other's durations while the step gets shorter.")
