@@ -48,3 +48,23 @@ def test_wd9_kernels_do_not_spill_and_leave_the_accumulation_registers_alone(tmp
                 regs = [int(r) for r in re.findall(r"\ba(\d+)\b", line)] + [int(b) for _, b in re.findall(r"\ba\[(\d+):(\d+)\]", line)]
                 limit = 64 if "wd9_tail" in kernel else 0
                 assert regs and max(regs) < limit, f"{kernel}: compiler code touches an accumulation register of the asm statements: {line.strip()}"
+
+
+def test_two_wave_weights_direct_kernels_fit_two_per_simd_without_scratch(tmp_path):
+    """csrc/conv_wd.h's kernels run two waves per SIMD: 256 registers each and no scratch (the fused tail sits AT 256 since its
+    line-store epilogue; an edit that tips it over spills into scratch inside the chunk loop - it did during round 4)."""
+    import proben_amd  # noqa: F401
+    from proben_amd import build
+    src = os.path.join(build.CSRC, "conv_wd.hip")
+    out = tmp_path / "conv_wd.s"
+    cmd = [build.hipcc(), "--offload-arch=" + build.ARCH, "-O3", "-std=c++17", "-x", "hip", "-S", "--cuda-device-only", src, "-o", str(out),
+           "-I", os.path.join(ROOT, "include"), "-I", build.CSRC] + build.EXTRA.get("conv_wd.hip", build.EXTRA["default"])
+    subprocess.check_call(cmd)
+    text = out.read_text()
+    seen = 0
+    for name, body in re.findall(r"\.amdhsa_kernel (\S*conv3x3_wd_kernel\S*)(.*?)\.end_amdhsa_kernel", text, flags=re.S):
+        seen += 1
+        assert re.search(r"\.amdhsa_private_segment_fixed_size 0\b", body), name + ": scratch in use"
+        m = re.search(r"\.amdhsa_next_free_vgpr (\d+)", body)
+        assert m and int(m.group(1)) <= 256, name
+    assert seen >= 3, "pure, fused-head and fused-tail instantiations expected"
