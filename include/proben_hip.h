@@ -123,12 +123,14 @@ int pe_conv2d_nhwc_f16(const void* input, const void* weight, const float* bias,
  * output with row stride out_stride (0 = Cout).
  * ------------------------------------------------------------------------------------------- */
 int pe_conv_wd_supported(int32_t kernel, int32_t stride, int32_t H, int32_t W, int32_t Cin, int32_t Cout);
-/* Two kernel generations stand behind pe_conv3x3_wd_f16 and pe_bottleneck_tail_wd_f16: two waves per SIMD, one tile per workgroup
- * (csrc/conv_wd.h) and one wave per SIMD with 256 accumulators in the AGPRs, PERSISTENT workgroups (csrc/conv_wd9.h for image
- * widths 64 / 128 / 256 from 128 tiles on - same bits as the other generation; csrc/conv_wd9_tail.h for image width 64, OPT-IN:
- * DESIGN.md 10.4; either is chosen by geometry only, never by batch size).  A persistent kernel occupies every CU it runs on for its whole duration.  A caller that runs `streams`
- * detectors concurrently on as many HIP streams (proben_amd/pipeline.py) says so here: the fused-tail kernel, when enabled, then takes
- * 256 / streams workgroups, leaving the other CUs to the other streams' launches (measured: profiles/r04_pipeline_ab_*.txt).
+/* Two kernel generations stand behind pe_conv3x3_wd_f16, pe_conv3x3_wd_rpn_head_f16 and pe_bottleneck_tail_wd_f16: two waves per SIMD,
+ * one tile per workgroup (csrc/conv_wd.h), and one wave per SIMD with 256 accumulators in the AGPRs and PERSISTENT workgroups
+ * (csrc/conv_wd9.h: the pure 3x3 and the fused RPN head at image widths 64 / 128 / 256 from 128 tiles of 256 pixels on - the same
+ * bits as the two-wave kernels, so the size rule may look at the batch; csrc/conv_wd9_tail.h: the fused tail at image width 64,
+ * OPT-IN, DESIGN.md 10.4, chosen by geometry only because its bits differ from the two-wave tail's).
+ * A persistent kernel occupies every CU it runs on for its whole duration.  A caller that runs `streams` detectors concurrently on
+ * as many HIP streams (proben_amd/pipeline.py) says so here: the opt-in fused-tail kernel, when enabled, then takes 256 / streams
+ * workgroups, leaving the other CUs to the other streams' launches (measured: profiles/r04_pipeline_ab_*.txt).
  * Process-global, affects launches issued afterwards; 1 = a launch has the chip to itself (default).  Never changes results. */
 int pe_conv_wd_set_concurrent_streams(int32_t streams);
 /* weight: [Cout][3][3][Cin] fp16 (the layout pe_conv2d_nhwc_f16 takes); packed: Cout*9*Cin halfs */
