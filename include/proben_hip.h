@@ -269,6 +269,16 @@ int pe_grid_anchors(const float* cell_anchors, int32_t num_cell_anchors, int32_t
                     float offset, float* out, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Fused SGD-with-momentum step over flat fp32 buffers (training half).  Replaces the per-parameter loop of the
+ * torch.optim.SGD that solver/build.py:93-133 builds (momentum, per-group lr / weight decay, dampening 0, no Nesterov) behind
+ * DefaultTrainer (engine/defaults.py:250-262):  d = grad * grad_scale + weight_decay * p;  buf = first_step ? d : momentum * buf + d;
+ * p -= lr * buf;  fp16_shadow (optional, [n] halfs) = (half)p in the same pass.  grad_scale folds DDP's 1 / world_size and the
+ * inverse loss scale.  All pointers 16-byte aligned (shadow 8): one call per parameter group of a flat buffer.
+ * ------------------------------------------------------------------------------------------- */
+int pe_sgd_momentum_f32(float* params, const float* grads, float* momentum_buf, void* fp16_shadow, int64_t n, float lr,
+                        float momentum, float weight_decay, float grad_scale, int32_t first_step, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * ROIAlign forward over NHWC feature maps.  Replaces roi_align_forward of detectron2._C
  * (layers/csrc/ROIAlign/ROIAlign.h:54-84, ROIAlign_cuda.cu:12-139,310-366; same arithmetic as
  * ROIAlign_cpu.cpp:22-218) and, with num_levels == 4, ROIPooler.forward + assign_boxes_to_levels

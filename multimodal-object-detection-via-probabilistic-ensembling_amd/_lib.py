@@ -43,6 +43,7 @@ SIGNATURES = {
     "pe_gather_boxes": [c_void_p] * 4 + [c_int] * 3 + [c_void_p] * 3,
     "pe_roi_align_nhwc": [c_void_p] * 3 + [c_int] * 4 + [c_void_p] + [c_int] * 3 + [c_void_p] + [c_int] * 4 + [c_void_p] * 3,
     "pe_roi_align_nhwc_sorted": [c_void_p] * 3 + [c_int] * 4 + [c_void_p] + [c_int] + [c_void_p] + [c_int] * 4 + [c_void_p] * 4,
+    "pe_sgd_momentum_f32": [c_void_p] * 4 + [ctypes.c_int64] + [ctypes.c_float] * 4 + [c_int, c_void_p],
     "pe_roi_align_backward_nhwc": [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     "pe_boxhead_candidates": [c_void_p, c_int, c_int, c_int, c_int] + [c_void_p] * 4 + [c_float, c_float, c_int] + [c_void_p] * 8,
     "pe_cocoeval_bbox": [c_void_p] * 6 + [ctypes.c_int64] + [c_void_p] * 4 + [ctypes.c_int64, c_int, c_int, c_void_p, c_int,

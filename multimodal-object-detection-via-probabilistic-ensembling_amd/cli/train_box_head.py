@@ -1,0 +1,76 @@
+"""Fine-tune the box head (incl. the Gaussian-NLL variance head) of a Faster R-CNN on frozen features, one process per GPU - the
+MI355X-native slice of demo/FLIR/demo_train_FLIR.py (DefaultTrainer + DistributedDataParallel + SGD).  No FLIR annotations exist
+offline, so the default data are synthetic labelled frames (`synthetic.labelled_frames`: rectangles whose texture encodes their class);
+a real run passes its own (frames, boxes, classes) iterator to `finetune.BoxHeadFineTuner.step`.
+
+    python -m proben_amd.cli.train_box_head --steps 200 --images-per-step 4 --world-size 2 --out head.pt [--weights model.pth]
+"""
+import argparse
+import json
+import sys
+import time
+
+import torch
+
+from .. import comm, launch
+from ..finetune import BoxHeadFineTuner, warmup_lr
+
+
+def parse(argv):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--images-per-step", type=int, default=4, help="per rank (SOLVER.IMS_PER_BATCH / world size)")
+    ap.add_argument("--lr", type=float, default=0.001, help="SOLVER.BASE_LR (demo_train_FLIR.py:62)")
+    ap.add_argument("--clip-grad-norm", type=float, default=1.0, help="SOLVER.CLIP_GRADIENTS (norm, type 2) over the whole head; 0 = off like the reference's default")
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--depth", type=int, default=101)
+    ap.add_argument("--num-classes", type=int, default=3)
+    ap.add_argument("--weights", default="", help="state dict (.pth / .pkl / the tests' .npz fixture); default: seeded random")
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--world-size", type=int, default=1)
+    ap.add_argument("--device", default="cuda")
+    ap.add_argument("--out", default="")
+    return ap.parse_args(argv)
+
+
+def main(cmd=None):
+    from ..data import resize_shortest_edge_shape
+    from ..rcnn import DetectorConfig, GeneralizedRCNN
+    from ..synthetic import labelled_frames, synthetic_state_dict
+    argv = list(cmd) if cmd is not None else sys.argv[1:]
+    args = parse(argv)
+    launch.maybe_self_launch(args.world_size, argv, module="proben_amd.cli.train_box_head", device=args.device)
+    rank, world, dev = launch.init_distributed(args.device, expect_world=args.world_size)
+    cfg = DetectorConfig(num_classes=args.num_classes)      # the depth is read off the state dict
+    if args.weights:
+        from ..weights import load_state_dict_file
+        sd = load_state_dict_file(args.weights)
+    else:
+        sd = synthetic_state_dict(args.depth, 3, args.num_classes, seed=args.seed)
+    model = GeneralizedRCNN(cfg, sd, device=dev)
+    tuner = BoxHeadFineTuner(model, lr=args.lr, seed=args.seed, init_from_model=bool(args.weights), clip_grad_norm=args.clip_grad_norm)
+    new_hw = resize_shortest_edge_shape(512, 640, 800, 1333)
+    log, t0 = [], time.time()
+    for step in range(args.steps):
+        # every rank draws its own frames (the reference's TrainingSampler shards an infinite stream by rank)
+        frames, gts = labelled_frames(args.images_per_step, seed=args.seed * 100003 + step * world + rank + 1)
+        losses = tuner.step(torch.from_numpy(frames).to(dev), [torch.from_numpy(b) for b, _ in gts], [torch.from_numpy(c) for _, c in gts],
+                            resize_to=new_hw, lr=warmup_lr(args.lr, step, args.warmup))
+        log.append(losses)
+        if comm.is_main_process() and (step % 20 == 0 or step == args.steps - 1):
+            print(json.dumps({"step": step, **{k: round(v, 4) for k, v in losses.items()}}), flush=True)
+    torch.cuda.synchronize()
+    if comm.is_main_process():
+        dt = time.time() - t0
+        print(json.dumps({"steps": args.steps, "world_size": world, "images_per_s": round(args.steps * args.images_per_step * world / dt, 1)}))
+        if args.out:
+            tuner.export()
+            f = tuner.head.flat
+            torch.save({n: f[n].detach().cpu() for n in f.names}, args.out)
+    if comm.is_distributed():
+        launch.shutdown()
+    return log
+
+
+if __name__ == "__main__":
+    main()

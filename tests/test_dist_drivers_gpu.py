@@ -131,3 +131,16 @@ def test_one_rank_rccl_group_runs_the_nccl_code_path(tmp_path):
     assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
     line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 1 and "all_gather_into_tensor" in line["config"]["collective"] and line["value"] > 0
+    # the box-head trainer: parameter broadcast + the bucketed gradient all-reduce over the one-rank RCCL group == the plain run
+    logs = []
+    for forced_run in (False, True):
+        e = dict(env)
+        if not forced_run:
+            e.pop("PROBEN_FORCE_DIST")
+        argv = ["--steps", "6", "--images-per-step", "2", "--seed", "4"]
+        cmd = launch.launch_command(argv, 1, launch.free_port(), module="proben_amd.cli.train_box_head") if forced_run else \
+            [sys.executable, "-m", "proben_amd.cli.train_box_head"] + argv
+        p = subprocess.run(cmd, capture_output=True, text=True, env=e, timeout=900, cwd=ROOT)
+        assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+        logs.append([json.loads(l) for l in p.stdout.splitlines() if l.startswith('{"step"')])
+    assert logs[0] and logs[0] == logs[1], logs

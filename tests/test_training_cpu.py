@@ -49,3 +49,125 @@ def test_empty_batch_and_l1_limit():
     a, b = torch.tensor([0.0, 2.0, -3.0]), torch.tensor([1.0, 0.0, 0.0])
     assert torch.equal(smooth_l1_loss(a, b, 0.0), torch.tensor([1.0, 2.0, 3.0]))
     np.testing.assert_allclose(smooth_l1_loss(a, b, 4.0).numpy(), [0.125, 0.5, 1.125])
+
+
+# ---- round 4: flat parameters and the bucketed gradient all-reduce (DDP's job) over gloo, world size 2 -------------------------------
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _toy(flat, x):
+    h = torch.relu(x @ flat["l1.weight"].t() + flat["l1.bias"])
+    h = torch.relu(h @ flat["l2.weight"].t() + flat["l2.bias"])
+    return (h @ flat["l3.weight"].t() + flat["l3.bias"]).pow(2).mean()
+
+
+_SHAPES = {"l1.weight": (7, 5), "l1.bias": (7,), "l2.weight": (6, 7), "l2.bias": (6,), "l3.weight": (3, 6), "l3.bias": (3,), "unused.weight": (2, 2)}
+
+
+def _ddp_worker(rank, world, port, tmp):
+    import os
+    import torch.distributed as dist
+    from proben_amd.training import BucketedGradAllReduce, FlatParams
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    flat = FlatParams(_SHAPES, "cpu")
+    g = torch.Generator().manual_seed(100 + rank)            # ranks start DIFFERENT: the reducer broadcasts rank 0's parameters
+    with torch.no_grad():
+        flat.master.copy_(torch.randn(flat.numel, generator=g))
+    red = BucketedGradAllReduce(flat, bucket_bytes=64)       # tiny buckets: several collectives per step
+    x = torch.randn(9, 5, generator=torch.Generator().manual_seed(7 + rank))
+    flat.zero_grad()
+    _toy(flat, x).backward()
+    own = flat.grad.clone()
+    scale = red.finish()
+    torch.save({"master": flat.master.clone(), "own": own, "sum": flat.grad.clone(), "scale": scale, "order": red.last_order,
+                "buckets": red.buckets, "x": x}, os.path.join(tmp, f"r{rank}.pt"))
+    # a second step works the same (counters were reset)
+    flat.zero_grad()
+    _toy(flat, x).backward()
+    assert red.finish() == 0.5
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucketed_grad_all_reduce_world_2_gloo(tmp_path):
+    """BucketedGradAllReduce = DistributedDataParallel for FlatParams: rank 0's parameters everywhere, every rank ends with the SUM of
+    the ranks' gradients and the factor 1 / world; buckets are contiguous, cover the buffer, fire in backward order (last layer
+    first), and the bucket of a parameter that got no gradient is reduced at finish() so that the ranks stay in step."""
+    import torch.multiprocessing as mp
+    from proben_amd.training import FlatParams
+    mp.spawn(_ddp_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (torch.load(tmp_path / f"r{r}.pt", weights_only=False) for r in (0, 1))
+    assert torch.equal(r0["master"], r1["master"])
+    ref = FlatParams(_SHAPES, "cpu")
+    with torch.no_grad():
+        ref.master.copy_(torch.randn(ref.numel, generator=torch.Generator().manual_seed(100)))
+    assert torch.equal(ref.master, r0["master"])
+    torch.testing.assert_close(r0["sum"], r0["own"] + r1["own"], rtol=0, atol=1e-6)
+    assert torch.equal(r0["sum"], r1["sum"]) and r0["scale"] == 0.5
+    # each rank's own gradient is what autograd gives for its batch with the broadcast parameters
+    for r in (r0, r1):
+        ref.zero_grad()
+        _toy(ref, r["x"]).backward()
+        torch.testing.assert_close(ref.grad, r["own"], rtol=0, atol=1e-6)
+    b = r0["buckets"]
+    assert len(b) >= 3 and b[0][1] == ref.numel and b[-1][0] == 0 and all(b[i][0] == b[i + 1][1] for i in range(len(b) - 1))
+    fired = [k for k in r0["order"]]
+    assert sorted(fired) == list(range(len(b)))
+    assert fired.index(0) == len(fired) - 1, fired
+    assert fired[:-1] == sorted(fired[:-1]), fired                                   # backward order = ascending bucket index
+
+
+def test_flat_params_views_and_group_runs():
+    from proben_amd.training import FlatParams
+    f = FlatParams({"a.weight": (3, 5), "b.weight": (2, 3), "a.bias": (3,), "b.bias": (2,)}, "cpu")
+    assert f.numel % 4 == 0 and all(o % 4 == 0 for o, _ in f.offsets.values())
+    assert f.runs() == [("weights", 0, 24), ("bias", 24, 8)]
+    with torch.no_grad():
+        f["a.weight"].fill_(1.5)
+    assert float(f.master[:15].sum()) == 22.5 and float(f.master[15]) == 0.0
+    f.refresh_shadow()
+    assert f.half("a.weight").dtype == torch.float16 and float(f.half("a.weight").sum()) == 22.5
+    (f["a.weight"].sum() * 2).backward()
+    assert float(f.grad[:15].sum()) == 30.0 and f["a.weight"].grad.data_ptr() == f.grad.data_ptr()
+
+
+def test_label_and_sample_proposals_follows_the_reference_rules():
+    """finetune.label_and_sample_proposals against the rules of ROIHeads.label_and_sample_proposals / subsample_labels / Matcher
+    (roi_heads.py:130-285, sampling.py:7-50): ground truth appended (each gt box is its own IoU-1 match), IoU >= 0.5 -> the gt's class,
+    else background K; at most int(S x 0.25) foreground rows, the rest background, fewer rows when the image runs out; an image without
+    ground truth is background only; the same generator state gives the same sample."""
+    from proben_amd.finetune import label_and_sample_proposals, pairwise_iou
+    K, S = 3, 32
+    g = torch.Generator().manual_seed(1)
+    xy = torch.rand(3, 50, 2, generator=g) * 200
+    props = torch.cat([xy, xy + 30 + torch.rand(3, 50, 2, generator=g) * 60], 2)
+    cnt = torch.tensor([50, 20, 6], dtype=torch.int32)
+    gtb = [torch.tensor([[10.0, 10, 80, 90], [100, 120, 180, 200]]), torch.zeros(0, 4), torch.tensor([[20.0, 30, 90, 100]])]
+    gtc = [torch.tensor([0, 2]), torch.zeros(0, dtype=torch.long), torch.tensor([1])]
+    out1 = label_and_sample_proposals(props, cnt, gtb, gtc, K, S, generator=torch.Generator().manual_seed(9))
+    out2 = label_and_sample_proposals(props, cnt, gtb, gtc, K, S, generator=torch.Generator().manual_seed(9))
+    assert all(torch.equal(a, b) for a, b in zip(out1, out2))
+    boxes, live, classes, matched = out1
+    assert live.tolist() == [32, 20, 7]                         # 50 + 2 candidates -> 32; 20 proposals, no gt; 6 + 1 candidates
+    for n in range(3):
+        m = int(live[n])
+        fg = classes[n, :m] < K
+        assert int(fg.sum()) <= int(S * 0.25)
+        if len(gtb[n]):
+            iou = pairwise_iou(gtb[n], boxes[n, :m])
+            best, idx = iou.max(0)
+            assert torch.equal(fg, best >= 0.5)
+            assert torch.equal(classes[n, :m][fg], gtc[n][idx][fg])
+            assert torch.equal(matched[n, :m][fg], gtb[n][idx][fg])
+        else:
+            assert not fg.any()
+        assert torch.all(classes[n, m:] == K) and float(boxes[n, m:].abs().sum()) == 0
+    # the appended ground truth is sampled as foreground when there is room: image 2 has 7 candidates, all kept, one of them is the gt box
+    assert any(torch.equal(boxes[2, i], gtb[2][0]) and int(classes[2, i]) == 1 for i in range(7))

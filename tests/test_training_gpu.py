@@ -1,0 +1,161 @@
+"""Training half on the device: the fused SGD kernel against torch.optim.SGD, the FC layers' forward / backward on the
+gfx950 GEMM against torch autograd in fp32, and whole box-head training steps against a stock PyTorch re-implementation."""
+import math
+
+import pytest
+import torch
+
+import proben_amd  # noqa: F401
+from proben_amd.modeling import Box2BoxTransform
+from proben_amd.training import BoxHead, BucketedGradAllReduce, FastRCNNLosses, FlatParams, FusedSGD, HipLinear, box_head_train_step
+
+pytestmark = pytest.mark.gpu
+
+
+def test_fused_sgd_matches_torch_optim_sgd_with_groups_and_refreshes_the_fp16_shadow():
+    """pe_sgd_momentum_f32 over the flat buffers == torch.optim.SGD with the parameter groups of solver/build.py:93-133 (bias group with
+    its own lr factor and weight decay), tensors whose sizes are not multiples of 4, grad_scale (DDP mean x inverse loss scale) folded
+    in; after every step the fp16 shadow is the rounded master and the padding elements stay zero."""
+    shapes = {"a.weight": (37, 19), "b.weight": (5, 3), "a.bias": (37,), "b.bias": (5,)}
+    flat = FlatParams(shapes, "cuda")
+    g = torch.Generator().manual_seed(3)
+    with torch.no_grad():
+        for n in flat.names:
+            flat[n].copy_(torch.randn(shapes[n], generator=g).cuda())
+    ref = {n: flat[n].detach().clone().requires_grad_() for n in flat.names}
+    opt_ref = torch.optim.SGD([{"params": [ref[n]], "lr": 0.05 * (2.0 if n.endswith("bias") else 1.0), "weight_decay": 0.0 if n.endswith("bias") else 0.01}
+                               for n in flat.names], 0.05, momentum=0.9)
+    opt = FusedSGD(flat, lr=0.05, momentum=0.9, weight_decay=0.01, bias_lr_factor=2.0, weight_decay_bias=0.0)
+    scale = 1.0 / (2 * 1024.0)
+    for step in range(4):
+        flat.zero_grad()
+        for n in flat.names:
+            gr = torch.randn(shapes[n], generator=g).cuda()
+            flat[n].grad.copy_(gr / scale)              # what backward leaves: summed over 2 ranks, loss-scaled
+            ref[n].grad = gr.clone()
+        opt.step(grad_scale=scale)
+        opt_ref.step()
+        for n in flat.names:
+            torch.testing.assert_close(flat[n].detach(), ref[n].detach(), rtol=2e-6, atol=2e-7)
+            assert torch.equal(flat.half(n), flat[n].detach().half())
+    pad = torch.ones(flat.numel, dtype=torch.bool, device="cuda")
+    for n in flat.names:
+        o, cnt = flat.offsets[n]
+        pad[o:o + cnt] = False
+    assert float(flat.master[pad].abs().sum()) == 0.0 and float(flat.momentum[pad].abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize("M,K,N,relu", [(96, 128, 192, True), (50, 64, 64, False), (512, 12544, 1024, True)])
+def test_hip_linear_forward_and_backward_match_torch_autograd(M, K, N, relu):
+    """HipLinear: y, dX, dW, db from three launches of the MFMA GEMM against torch fp32 autograd on the same fp16-rounded operands
+    (fp16 products, fp32 accumulation: 4e-3 relative to the tensor's scale; dX is returned in fp16)."""
+    g = torch.Generator().manual_seed(M + K)
+    x = (torch.randn(M, K, generator=g) / 2).cuda().half()
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    dy = torch.randn(M, N, generator=g).cuda()
+    xr = x.float().requires_grad_()
+    wr = w.half().float().requires_grad_()
+    br = b.clone().requires_grad_()
+    yr = torch.nn.functional.linear(xr, wr, br)
+    yr = yr.relu() if relu else yr
+    yr.backward(dy.half().float())
+    xh = x.clone().requires_grad_()
+    wp, bp = w.clone().requires_grad_(), b.clone().requires_grad_()
+    y = HipLinear.apply(xh, wp, bp, w.half(), relu, True)
+    y.backward(dy)
+
+    def close(a, r, tol=4e-3):
+        scale = float(r.abs().max()) + 1e-12
+        assert float((a.float() - r).abs().max()) <= tol * scale, (float((a.float() - r).abs().max()), scale)
+    close(y, yr.detach())
+    close(xh.grad, xr.grad, 6e-3)
+    close(wp.grad, wr.grad, 6e-3)
+    close(bp.grad, br.grad)
+    assert wp.grad.dtype == torch.float32 and xh.grad.dtype == torch.float16
+
+
+def test_box_head_training_steps_follow_a_stock_pytorch_head():
+    """Five SGD steps of the box head (two FCs + scores / deltas / variance predictor, cross entropy + smooth L1 + Gaussian NLL,
+    momentum 0.9, weight decay 1e-4) on frozen ROI features: the HIP path (GEMM forward / backward, fused SGD, loss scale 1024) against
+    the same head in stock fp32 PyTorch with torch.optim.SGD from the same initial values.  The losses agree to 2 % at every step and
+    fall; every tensor's accumulated update stays within 3 % (Frobenius norm; measured < 1 %) of the reference's - fp16 activation gradients."""
+    K, R, C = 3, 256, 256
+    dev = "cuda"
+    g = torch.Generator().manual_seed(11)
+    pooled = (torch.randn(R, 7, 7, C, generator=g).relu() / 2).to(dev).half()
+    xy = torch.rand(R, 2, generator=g) * 300
+    prop = torch.cat([xy, xy + 20 + torch.rand(R, 2, generator=g) * 100], 1).to(dev)
+    gt = prop + torch.randn(R, 4, generator=g).to(dev) * 4
+    gt[:, 2:] = torch.maximum(gt[:, 2:], gt[:, :2] + 1)
+    cls = torch.randint(0, K + 1, (R,), generator=g).to(dev)
+    t = Box2BoxTransform(weights=(10.0, 10.0, 5.0, 5.0))
+    head = BoxHead(49 * C, K, dev, seed=5)
+    ref = {n: head.flat[n].detach().clone().requires_grad_() for n in head.flat.names}
+    start = {n: ref[n].detach().clone() for n in ref}
+    opt_ref = torch.optim.SGD([{"params": [ref[n]], "weight_decay": 1e-4} for n in ref], 0.02, momentum=0.9)
+    opt = FusedSGD(head.flat, lr=0.02, momentum=0.9, weight_decay=1e-4)
+    red = BucketedGradAllReduce(head.flat)        # world size 1: no collective, the hooks and the bookkeeping still run
+    hist, hist_ref = [], []
+    for step in range(5):
+        hist.append(box_head_train_step(head, opt, red, pooled, prop, gt, cls, t, loss_scale=1024.0))
+        x = pooled.reshape(R, -1).float()
+        x = torch.relu(x @ ref["fc1.weight"].t() + ref["fc1.bias"])
+        x = torch.relu(x @ ref["fc2.weight"].t() + ref["fc2.bias"])
+        h = x @ ref["predictor.weight"].t() + ref["predictor.bias"]
+        losses = FastRCNNLosses(t, h[:, :K + 1], h[:, K + 1:K + 1 + 4 * K], torch.exp(h[:, K + 1 + 4 * K:head.cols]), prop, gt, cls).losses()
+        opt_ref.zero_grad()
+        sum(losses.values()).backward()
+        opt_ref.step()
+        hist_ref.append({k: float(v) for k, v in losses.items()})
+    for a, b in zip(hist, hist_ref):
+        for k in b:
+            assert abs(a[k] - b[k]) <= 0.02 * abs(b[k]) + 1e-3, (k, hist, hist_ref)
+    tot = [sum(h.values()) for h in hist]
+    assert tot[-1] < tot[0], tot
+    assert red.last_order == list(range(len(red.buckets)))
+    ratios = {}
+    for n in ref:
+        upd_ref = ref[n].detach() - start[n]
+        upd = head.flat[n].detach() - start[n]
+        assert float(upd_ref.norm()) > 0
+        ratios[n] = float((upd - upd_ref).norm() / upd_ref.norm())       # fp16 activation gradients: a few percent of the update
+        assert torch.equal(head.flat.half(n), head.flat[n].detach().half())
+    assert max(ratios.values()) <= 0.03, ratios          # measured: 0.0083 (fc1.weight)
+    print("relative update error per tensor:", {k: round(v, 4) for k, v in ratios.items()})
+
+
+def test_fine_tuning_the_box_head_on_frozen_features_learns_the_synthetic_classes(golden_dir):
+    """finetune.BoxHeadFineTuner end to end: R101-FPN with the fixture's fitted RPN (tests/golden/pseudo_heads_r101.npz) and a FRESH
+    random box head; 150 SGD steps (lr 0.005, 20 warm-up steps) on synthetic labelled frames (4 frames x 512 sampled proposals per step,
+    HIP ROIAlign / GEMM forward and backward / fused SGD); the classification loss halves (measured 1.30 -> 0.47), every loss stays
+    finite, and after `export()` the detector - inference path untouched otherwise - finds objects on 16 held-out frames: AP50 > 15
+    (measured 28) where the fresh head scores ~0.  (lr 0.02 diverges on these random frozen features; the reference trains at 0.001.)"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from parity_map import coco_stats, hip_rows, load_fixture
+    from proben_amd.data import resize_shortest_edge_shape
+    from proben_amd.finetune import BoxHeadFineTuner, warmup_lr
+    from proben_amd.rcnn import DetectorConfig, GeneralizedRCNN
+    from proben_amd.synthetic import labelled_frames
+    _, sd, _, _ = load_fixture(golden_dir)
+    model = GeneralizedRCNN(DetectorConfig(), sd)
+    tuner = BoxHeadFineTuner(model, lr=0.005, seed=3, init_from_model=False)
+    held, held_gt = labelled_frames(16, seed=9001)
+    tuner.export()                                                       # the fresh head in the detector: nothing to find yet
+    before = coco_stats(held_gt, hip_rows(model, held))[1] * 100
+    new_hw = resize_shortest_edge_shape(512, 640, 800, 1333)
+    hist = []
+    for step in range(150):
+        frames, gts = labelled_frames(4, seed=5000 + step)
+        hist.append(tuner.step(torch.from_numpy(frames).cuda(), [torch.from_numpy(b) for b, _ in gts], [torch.from_numpy(c) for _, c in gts],
+                               resize_to=new_hw, lr=warmup_lr(0.005, step, 20)))
+    first, last = sum(h["loss_cls"] for h in hist[:5]) / 5, sum(h["loss_cls"] for h in hist[-5:]) / 5
+    assert last < first / 2, (first, last)
+    assert all(math.isfinite(v) for h in hist for v in h.values())
+    tuner.export()
+    after = coco_stats(held_gt, hip_rows(model, held))[1] * 100
+    print(f"AP50 on 16 held-out frames: {before:.1f} -> {after:.1f}; loss_cls {first:.3f} -> {last:.3f}; "
+          f"box {hist[0]['loss_box_reg']:.3f} -> {hist[-1]['loss_box_reg']:.3f}; gaussian {hist[0]['gaussian_loss']:.3f} -> {hist[-1]['gaussian_loss']:.3f}")
+    assert before < 2 and after > 15, (before, after)
