@@ -101,6 +101,24 @@ class BoxHeadFineTuner:
             w.predictor = (f.half("predictor.weight")[:n].clone().contiguous(), f["predictor.bias"].detach()[:n].clone())
             w.has_var = True
 
+    def state_dict(self):
+        """What a resumed run needs (the reference's DetectionCheckpointer saves model + optimizer + scheduler, engine/defaults.py:264-275):
+        master weights, momentum, the optimiser's step count and the sampler's generator state."""
+        f = self.head.flat
+        return {"names": list(f.names), "shapes": dict(f.shapes), "master": f.master.detach().cpu().clone(), "momentum": f.momentum.cpu().clone(),
+                "steps": self.opt.steps, "lr": self.opt.lr, "generator": self.gen.get_state()}
+
+    def load_state_dict(self, sd):
+        f = self.head.flat
+        if list(sd["names"]) != list(f.names) or {k: tuple(v) for k, v in sd["shapes"].items()} != f.shapes:
+            raise ValueError("checkpoint of a different box head (tensor names / shapes differ)")
+        with torch.no_grad():
+            f.master.copy_(sd["master"].to(f.master.device))
+            f.momentum.copy_(sd["momentum"].to(f.momentum.device))
+        f.refresh_shadow()
+        self.opt.steps, self.opt.lr = int(sd["steps"]), float(sd["lr"])
+        self.gen.set_state(sd["generator"])
+
     @torch.no_grad()
     def _features(self, frames, resize_to):
         det = self.model.forward_batch(frames, resize_to=resize_to, keep_intermediates=True)
@@ -131,9 +149,21 @@ class BoxHeadFineTuner:
         return losses
 
 
-def warmup_lr(base_lr, step, warmup_iters=100, warmup_factor=0.001):
-    """WarmupMultiStepLR's linear warm-up (solver/lr_scheduler.py:104-130) without the later decays (short fine-tuning runs)."""
+def multistep_lr(base_lr, step, milestones=(), gamma=0.1, warmup_iters=1000, warmup_factor=0.001, warmup_method="linear"):
+    """WarmupMultiStepLR (solver/lr_scheduler.py:16-51, 86-115; SOLVER.STEPS / GAMMA / WARMUP_ITERS / WARMUP_FACTOR / WARMUP_METHOD):
+    lr = base x warm-up factor x gamma ** (number of milestones <= step)."""
     if step >= warmup_iters:
-        return base_lr
-    alpha = step / warmup_iters
-    return base_lr * (warmup_factor * (1 - alpha) + alpha)
+        warm = 1.0
+    elif warmup_method == "constant":
+        warm = warmup_factor
+    elif warmup_method == "linear":
+        alpha = step / warmup_iters
+        warm = warmup_factor * (1 - alpha) + alpha
+    else:
+        raise ValueError(f"Unknown warmup method: {warmup_method}")
+    return base_lr * warm * gamma ** sum(1 for m in milestones if m <= step)
+
+
+def warmup_lr(base_lr, step, warmup_iters=100, warmup_factor=0.001):
+    """The linear warm-up alone (short fine-tuning runs)."""
+    return multistep_lr(base_lr, step, (), 0.1, warmup_iters, warmup_factor)

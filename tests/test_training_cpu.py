@@ -171,3 +171,22 @@ def test_label_and_sample_proposals_follows_the_reference_rules():
         assert torch.all(classes[n, m:] == K) and float(boxes[n, m:].abs().sum()) == 0
     # the appended ground truth is sampled as foreground when there is room: image 2 has 7 candidates, all kept, one of them is the gt box
     assert any(torch.equal(boxes[2, i], gtb[2][0]) and int(classes[2, i]) == 1 for i in range(7))
+
+
+def test_multistep_lr_is_warmup_multistep_lr():
+    """finetune.multistep_lr against torch's MultiStepLR x the reference's warm-up factor (solver/lr_scheduler.py:16-51, 86-115)."""
+    from proben_amd.finetune import multistep_lr, warmup_lr
+    base, miles, gamma, wi, wf = 0.02, (30, 45), 0.1, 10, 0.001
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.SGD([p], base)
+    sch = torch.optim.lr_scheduler.MultiStepLR(opt, list(miles), gamma)
+    for step in range(60):
+        warm = 1.0 if step >= wi else wf * (1 - step / wi) + step / wi
+        assert abs(multistep_lr(base, step, miles, gamma, wi, wf) - sch.get_last_lr()[0] * warm) < 1e-12, step
+        opt.step()
+        sch.step()
+    assert multistep_lr(base, 3, (), 0.1, 10, 0.5, "constant") == base * 0.5
+    assert warmup_lr(base, 0, 100) == base * 0.001 and warmup_lr(base, 100, 100) == base
+    import pytest
+    with pytest.raises(ValueError):
+        multistep_lr(base, 1, (), 0.1, 10, 0.1, "cosine")

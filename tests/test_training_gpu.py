@@ -159,3 +159,38 @@ def test_fine_tuning_the_box_head_on_frozen_features_learns_the_synthetic_classe
     print(f"AP50 on 16 held-out frames: {before:.1f} -> {after:.1f}; loss_cls {first:.3f} -> {last:.3f}; "
           f"box {hist[0]['loss_box_reg']:.3f} -> {hist[-1]['loss_box_reg']:.3f}; gaussian {hist[0]['gaussian_loss']:.3f} -> {hist[-1]['gaussian_loss']:.3f}")
     assert before < 2 and after > 15, (before, after)
+
+
+def test_fine_tuner_checkpoint_resume_is_exact(golden_dir):
+    """BoxHeadFineTuner.state_dict() / load_state_dict(): a run that is interrupted after three steps and resumed in a NEW tuner (master
+    weights, momentum, optimiser step count, the sampler's generator state) continues with the same bits as the uninterrupted run."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from parity_map import load_fixture
+    from proben_amd.data import resize_shortest_edge_shape
+    from proben_amd.finetune import BoxHeadFineTuner
+    from proben_amd.rcnn import DetectorConfig, GeneralizedRCNN
+    from proben_amd.synthetic import labelled_frames
+    _, sd, _, _ = load_fixture(golden_dir)
+    model = GeneralizedRCNN(DetectorConfig(), sd)
+    new_hw = resize_shortest_edge_shape(512, 640, 800, 1333)
+
+    def run(tuner, steps):
+        out = []
+        for step in steps:
+            frames, gts = labelled_frames(2, seed=7000 + step)
+            out.append(tuner.step(torch.from_numpy(frames).cuda(), [torch.from_numpy(b) for b, _ in gts], [torch.from_numpy(c) for _, c in gts], resize_to=new_hw))
+        return out
+    a = BoxHeadFineTuner(model, lr=0.002, seed=8, init_from_model=False)
+    run(a, range(3))
+    ckpt = a.state_dict()
+    rest_a = run(a, range(3, 6))
+    b = BoxHeadFineTuner(model, lr=0.5, seed=99, init_from_model=False)      # everything that matters comes from the checkpoint
+    b.load_state_dict(ckpt)
+    rest_b = run(b, range(3, 6))
+    assert rest_a == rest_b
+    assert torch.equal(a.head.flat.master, b.head.flat.master) and torch.equal(a.head.flat.momentum, b.head.flat.momentum)
+    with pytest.raises(ValueError):
+        ckpt["names"] = ckpt["names"][::-1]
+        b.load_state_dict(ckpt)
