@@ -190,3 +190,49 @@ def test_multistep_lr_is_warmup_multistep_lr():
     import pytest
     with pytest.raises(ValueError):
         multistep_lr(base, 1, (), 0.1, 10, 0.1, "cosine")
+
+
+def test_losses_and_proposal_labelling_reproduce_the_reference_generated_goldens(golden_dir):
+    """tests/golden/training_cases.npz was GENERATED from the reference's own code (tests/golden/gen_training.py: FastRCNNOutputs'
+    cross entropy and Gaussian NLL, Box2BoxTransform.get_deltas, Matcher + pairwise_iou, subsample_labels' counts).  FastRCNNLosses,
+    finetune.pairwise_iou and finetune.label_and_sample_proposals must reproduce it: losses to 1e-6, IoU matrix to 1e-6, every
+    proposal's class label exactly, the sampled foreground / background counts exactly."""
+    import os
+    from proben_amd.finetune import label_and_sample_proposals, pairwise_iou
+    z = np.load(os.path.join(golden_dir, "training_cases.npz"))
+    t = Box2BoxTransform(weights=(10.0, 10.0, 5.0, 5.0))
+    for case in range(3):
+        g = lambda k: torch.from_numpy(z[f"loss{case}_{k}"])
+        var = g("var") if z[f"loss{case}_var"].size else torch.zeros(0)
+        L = FastRCNNLosses(t, g("logits"), g("deltas"), var, g("prop"), g("gt"), g("cls"), smooth_l1_beta=float(z[f"loss{case}_beta"]))
+        np.testing.assert_allclose(t.get_deltas(g("prop"), g("gt")).numpy(), z[f"loss{case}_gt_deltas"], rtol=1e-6, atol=1e-6)
+        out = L.losses()
+        np.testing.assert_allclose(float(out["loss_cls"]), float(z[f"loss{case}_out_loss_cls"]), rtol=1e-6)
+        if var.numel():
+            np.testing.assert_allclose(float(out["gaussian_loss"]), float(z[f"loss{case}_out_gaussian_loss"]), rtol=1e-6)
+        else:
+            assert "gaussian_loss" not in out
+    for case in range(3):
+        gt, prop = torch.from_numpy(z[f"match{case}_gt"]), torch.from_numpy(z[f"match{case}_prop"])
+        np.testing.assert_allclose(pairwise_iou(gt, prop).numpy(), z[f"match{case}_iou"], rtol=1e-6, atol=1e-7)
+        P = len(prop)
+        cnt = torch.tensor([P], dtype=torch.int32)
+        gcls = torch.from_numpy(z[f"match{case}_gt_classes"])
+        # every candidate kept (S = P, no fraction cap): the labels are the Matcher's
+        b, live, cls, mg = label_and_sample_proposals(prop[None], cnt, [gt], [gcls], 3, batch_size_per_image=P, positive_fraction=1.0,
+                                                      append_gt=False, generator=torch.Generator().manual_seed(0))
+        assert int(live[0]) == P
+        want = torch.from_numpy(z[f"match{case}_classes"])
+        # rows come back as [foreground..., background...] in random order: compare per box
+        key = lambda bx: tuple(round(float(v), 3) for v in bx)
+        got = {key(b[0, i]): int(cls[0, i]) for i in range(P)}
+        assert got == {key(prop[i]): int(want[i]) for i in range(P)}
+        idx = torch.from_numpy(z[f"match{case}_idx"])
+        fg = cls[0] < 3
+        ref_gt = {key(prop[i]): key(gt[idx[i]]) for i in range(P) if int(want[i]) < 3}
+        assert {key(b[0, i]): key(mg[0, i]) for i in range(P) if fg[i]} == ref_gt
+        # the reference's sampler at 64 rows, 25 % foreground: the same counts
+        _, live, cls, _ = label_and_sample_proposals(prop[None], cnt, [gt], [gcls], 3, batch_size_per_image=64, positive_fraction=0.25,
+                                                     append_gt=False, generator=torch.Generator().manual_seed(1))
+        m = int(live[0])
+        assert int((cls[0, :m] < 3).sum()) == int(z[f"match{case}_npos"]) and int((cls[0, :m] == 3).sum()) == int(z[f"match{case}_nneg"])
