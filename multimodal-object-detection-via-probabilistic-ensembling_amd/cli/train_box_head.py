@@ -60,6 +60,9 @@ def main(cmd=None):
         if comm.is_main_process() and (step % 20 == 0 or step == args.steps - 1):
             print(json.dumps({"step": step, **{k: round(v, 4) for k, v in losses.items()}}), flush=True)
     torch.cuda.synchronize()
+    import hashlib
+    digest = hashlib.sha256(tuner.head.flat.master.detach().cpu().numpy().tobytes()).hexdigest()[:16]
+    print(json.dumps({"rank": rank, "weights_sha": digest, "last_loss_cls": round(log[-1]["loss_cls"], 6)}), flush=True)    # every rank: DDP keeps them equal
     if comm.is_main_process():
         dt = time.time() - t0
         print(json.dumps({"steps": args.steps, "world_size": world, "images_per_s": round(args.steps * args.images_per_step * world / dt, 1)}))

@@ -192,7 +192,13 @@ class BucketedGradAllReduce:
         for name in flat.names:
             flat[name].register_post_accumulate_grad_hook(lambda p, nm=name: self._ready(nm))
         if broadcast and self.collective:                     # DDP's initial parameter broadcast from rank 0
-            dist.broadcast(flat.master, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            src = dist.get_global_rank(group, 0) if group is not None else 0
+            if flat.master.is_cuda and dist.get_backend(group) == "gloo":
+                host = flat.master.cpu()
+                dist.broadcast(host, src=src, group=group)
+                flat.master.copy_(host)
+            else:
+                dist.broadcast(flat.master, src=src, group=group)
             flat.refresh_shadow()
 
     def _launch(self, b):
@@ -200,7 +206,14 @@ class BucketedGradAllReduce:
         self.launched[b] = True
         self.order.append(b)
         if self.collective:
-            self.handles.append(self.dist.all_reduce(self.flat.grad[lo:hi], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True))
+            view = self.flat.grad[lo:hi]
+            if view.is_cuda and self.dist.get_backend(self.group) == "gloo":
+                # ranks sharing one device for testing (PROBEN_DIST_BACKEND=gloo): stage through the host, synchronously
+                host = view.cpu()
+                self.dist.all_reduce(host, op=self.dist.ReduceOp.SUM, group=self.group)
+                view.copy_(host)
+            else:
+                self.handles.append(self.dist.all_reduce(view, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def _ready(self, name):
         b = self.bucket_of[name]

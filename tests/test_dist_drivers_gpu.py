@@ -144,3 +144,22 @@ def test_one_rank_rccl_group_runs_the_nccl_code_path(tmp_path):
         assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
         logs.append([json.loads(l) for l in p.stdout.splitlines() if l.startswith('{"step"')])
     assert logs[0] and logs[0] == logs[1], logs
+
+
+def test_world_size_2_box_head_training_keeps_the_ranks_in_step():
+    """cli/train_box_head.py --world-size 2 (two GPUs over RCCL; on a one-GPU box the two ranks share the device and the reducer's
+    collectives go over gloo): the ranks see DIFFERENT frames (their losses differ) and end with the SAME head, bit for bit - rank 0's
+    initial parameters were broadcast, every step applied the summed gradients x 1 / world on both - and that head differs from the
+    one a single rank trains on its own frames."""
+    import torch
+    env = _env(torch.cuda.device_count() >= 2)
+    runs = {}
+    for world in (2, 1):
+        p = _cli("train_box_head", ["--steps", "4", "--images-per-step", "2", "--seed", "6", "--world-size", str(world)], env)
+        rows = [json.loads(l) for l in p.stdout.splitlines() if l.startswith('{"rank"')]
+        assert len(rows) == world, (p.stdout[-1500:], p.stderr[-1500:])
+        runs[world] = {r["rank"]: r for r in rows}
+    two = runs[2]
+    assert two[0]["weights_sha"] == two[1]["weights_sha"]
+    assert two[0]["last_loss_cls"] != two[1]["last_loss_cls"]
+    assert runs[1][0]["weights_sha"] != two[0]["weights_sha"]
