@@ -10,7 +10,7 @@ kernels).  Round 4 adds what fine-tuning the box head on frozen features needs o
   * `FusedSGD`: torch.optim.SGD as solver/build.py:93-133 configures it, as ONE kernel per parameter group
     (csrc/optim.hip: momentum, weight decay, the 1 / world_size of DDP, the inverse loss scale and the fp16 shadow refresh fused);
   * `BoxHead` + `box_head_train_step`: FastRCNNConvFCHead + FastRCNNOutputLayers with this repository's variance head
-    (roi_heads/box_head.py, fast_rcnn.py:395-470) trained with the losses below.
+    (roi_heads/box_head.py:20-80, fast_rcnn.py:454-545) trained with the losses below.
 The detector's CONVOLUTION backward passes are not part of this build (the backbone stays frozen): inference is the hot path.
 
 The losses are plain tensor math on whatever device the tensors live on, like the reference's Python."""
@@ -284,7 +284,7 @@ class BoxHead:
         self.flat = FlatParams({"fc1.weight": (fc_dim, in_features), "fc2.weight": (fc_dim, fc_dim), "predictor.weight": (self.cols_padded, fc_dim),
                                 "fc1.bias": (fc_dim,), "fc2.bias": (fc_dim,), "predictor.bias": (self.cols_padded,)}, device)
         g = torch.Generator().manual_seed(seed)
-        with torch.no_grad():      # c2_xavier_fill for the FCs, normal(0.01 / 0.001 / 0.01) for cls_score / bbox_pred / var_pred (box_head.py:60-63, fast_rcnn.py:493-512)
+        with torch.no_grad():      # c2_xavier_fill for the FCs, normal(0.01 / 0.001 / 0.01) for cls_score / bbox_pred / var_pred (box_head.py:60-63, fast_rcnn.py:493-512: cls_score 0.01, bbox_pred 0.001, var_pred 0.01)
             for nm, fan in (("fc1.weight", in_features), ("fc2.weight", fc_dim)):
                 bound = math.sqrt(3.0 / fan)
                 self.flat[nm].copy_(((torch.rand(self.flat.shapes[nm], generator=g) * 2 - 1) * bound).to(device))
