@@ -60,3 +60,22 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".cpp", ".h")):
                 src = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+
+
+def test_argument_checks_answer_before_any_device_work(built_lib):
+    """Error behaviour of the C-ABI without a GPU: argument checks come first and explain themselves through pe_last_error()
+    (null pointers, misaligned flat buffers of the fused SGD step, a ROI order workspace that is missing, bad stream counts)."""
+    import proben_amd
+    L = proben_amd._lib.lib()
+    err = lambda: L.pe_last_error().decode()
+    assert L.pe_sgd_momentum_f32(None, None, None, None, 0, 0.1, 0.9, 0.0, 1.0, 1, None) == 0          # empty range: nothing to do
+    assert L.pe_sgd_momentum_f32(None, None, None, None, 8, 0.1, 0.9, 0.0, 1.0, 1, None) != 0 and "null pointer" in err()
+    assert L.pe_sgd_momentum_f32(4096 + 8, 4096, 4096, None, 8, 0.1, 0.9, 0.0, 1.0, 1, None) != 0 and "16-byte aligned" in err()
+    assert L.pe_sgd_momentum_f32(4096, 4096, 4096, 4096 + 4, 8, 0.1, 0.9, 0.0, 1.0, 1, None) != 0 and "16-byte aligned" in err()
+    assert L.pe_conv_wd_set_concurrent_streams(0) != 0 and "streams" in err()
+    assert L.pe_conv_wd_set_concurrent_streams(2) == 0 and L.pe_conv_wd_set_concurrent_streams(1) == 0
+    feats = (ctypes.c_void_p * 4)(4096, 4096, 4096, 4096)
+    hw = (ctypes.c_int32 * 8)(200, 256, 100, 128, 50, 64, 25, 32)
+    sc = (ctypes.c_float * 4)(0.25, 0.125, 0.0625, 0.03125)
+    st = L.pe_roi_align_nhwc_sorted(feats, hw, sc, 4, 2, 256, 0, 4096, 1000, None, 7, 7, 0, 1, 4096, None, None, None)
+    assert st != 0 and "order workspace" in err()
