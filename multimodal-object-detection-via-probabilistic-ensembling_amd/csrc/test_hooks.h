@@ -8,6 +8,8 @@ extern "C" {
  *   tile_bits (default 9 = 1|8):  1: 256-row block tiles (8 waves) for 3x3 launches with >= 512 such tiles   2: the same for 1x1
  *                                 4: two-stage pipeline in the generic 1x1 kernel   8: 256x256 two-stage kernel for long-K GEMMs
  *                                16: 256x256 kernel for every eligible launch
+ *                                32: persistent loader / consumer 1x1 kernel (csrc/conv1x1_ring.hip) for K >= 1024, Cout == 256 (res4 conv1)
+ *                                64: ... for every eligible 1x1 launch (stride 1, no residual, fp16 out, K >= 512, Cout % 256 == 0)
  *   reuse3x3 (default 1): 1 = kw-reuse 3x3 kernel, 0 = generic per-tap 3x3 kernel */
 int pe_test_set_conv_policy(int tile_bits, int reuse3x3);
 /* Which generation of the weights-direct kernels takes a launch.  Bit mask (default 1 | 8; the tail kernel is opt-in, csrc/conv_wd9.hip;
@@ -25,6 +27,10 @@ int pe_test_wd9_tail_takes(int H, int W, int Cin, int tail_cout);
 /* workgroups of the persistent kernels (multiples of 8 in 8 .. 256; 0 = leave unchanged; default 256 = one per CU): what leaving CUs
  * to the other detector's stream is worth (scripts/r04_ab2.sh) */
 int pe_test_set_wd9_wgs(int pure, int tail);
+/* workgroups of the persistent 1x1 ring kernel (default 256 = one per CU) */
+int pe_test_set_ring_wgs(int wgs);
+/* ablation builds of the ring kernel (csrc/conv1x1_ring.hip RingArgs::abl; non-zero = wrong results, timing only) */
+int pe_test_set_ring_ablation(int bits);
 #ifdef __cplusplus
 }
 #endif

@@ -377,59 +377,3 @@ def inference_on_dataset(model, data_loader, evaluator):
     logger.info("Total inference pure compute time: %.3f s (%.6f s / img per device)", compute, compute / n)
     results = evaluator.evaluate()
     return results if results is not None else {}
-
-
-def log_average_miss_rate(gt_per_frame, det_per_frame, iou_thresh=0.5, fppi_points=None):
-    """KAIST-style pedestrian metric (config 5).  PARITY UNPINNED: the reference calls
-    `evalKAIST.evaluation_script.evaluate` (demo/KAIST/demo_LAMR_KAIST.py:85,145), a package that is not in its
-    tree; this is the standard Caltech/KAIST protocol: per frame, detections in score order are greedily matched
-    to ground truth at IoU >= 0.5 (xywh boxes; matches to `ignore` boxes are neither TP nor FP, IoU against an
-    ignore box is intersection / detection area), then the miss rate is sampled at 9 FPPI points log-spaced in
-    [1e-2, 1e0] and averaged in log space.
-      gt_per_frame[i]  = list of (x, y, w, h, ignore)
-      det_per_frame[i] = list of (x, y, w, h, score)
-    Returns (lamr, miss_rates_at_points, fppi_points)."""
-    fppi_points = np.logspace(-2.0, 0.0, 9) if fppi_points is None else np.asarray(fppi_points)
-    scores, tps, fps = [], [], []
-    n_gt = 0
-    n_frames = len(gt_per_frame)
-    for gts, dets in zip(gt_per_frame, det_per_frame):
-        gts = np.asarray(gts, dtype=np.float64).reshape(-1, 5)
-        dets = np.asarray(dets, dtype=np.float64).reshape(-1, 5)
-        order = np.argsort(-dets[:, 4], kind="mergesort")
-        dets = dets[order]
-        gorder = np.argsort(gts[:, 4], kind="mergesort")      # real boxes first, ignore regions last
-        gts = gts[gorder]
-        n_gt += int((gts[:, 4] == 0).sum())
-        iou = bbox_iou_xywh(dets[:, :4], gts[:, :4], gts[:, 4] != 0)
-        taken = np.zeros(len(gts), dtype=bool)
-        for d in range(len(dets)):
-            best, m = iou_thresh, -1
-            for g in range(len(gts)):
-                if taken[g] and gts[g, 4] == 0:
-                    continue
-                if m > -1 and gts[m, 4] == 0 and gts[g, 4] != 0:
-                    break
-                if iou[d, g] < best:
-                    continue
-                best, m = iou[d, g], g
-            if m > -1 and gts[m, 4] != 0:
-                continue                                        # matched an ignore region: not counted
-            scores.append(dets[d, 4])
-            if m > -1:
-                taken[m] = True
-                tps.append(1); fps.append(0)
-            else:
-                tps.append(0); fps.append(1)
-    if n_gt == 0:
-        return float("nan"), np.full(len(fppi_points), np.nan), fppi_points
-    order = np.argsort(-np.asarray(scores), kind="mergesort")
-    tp = np.cumsum(np.asarray(tps)[order]) if len(order) else np.zeros(0)
-    fp = np.cumsum(np.asarray(fps)[order]) if len(order) else np.zeros(0)
-    fppi = fp / max(n_frames, 1)
-    mr = 1.0 - tp / n_gt
-    out = np.ones(len(fppi_points))
-    for i, ref in enumerate(fppi_points):
-        idx = np.nonzero(fppi <= ref)[0]
-        out[i] = mr[idx[-1]] if len(idx) else 1.0
-    return float(np.exp(np.mean(np.log(np.maximum(out, 1e-10))))), out, fppi_points
