@@ -21,8 +21,8 @@
 //     is done with stage s - 1, which is exactly the ring slot their next DMA overwrites;
 //   * out-of-run / out-of-image pixel rows use an out-of-range buffer offset: the bounds check returns zeros and fetches nothing;
 //   * the MFMA takes the WEIGHT fragment as A and the pixel fragment as B, and weight row perm(i) feeds MFMA row i, so a lane ends up
-//     with 16 CONSECUTIVE output channels of one pixel: two 16-byte stores per accumulator tile straight from registers (no LDS
-//     transposition - all 160 KiB belong to the rings).
+//     with 16 CONSECUTIVE output channels of one pixel; the epilogue turns that into whole 128-byte lines through a wave-private patch
+//     of the weight slot the tile has just finished with (all 160 KiB belong to the rings; one extra barrier per tile frees the slot).
 // Same products in the same K order with the same zero-initialised fp32 accumulators and bias added in the epilogue as
 // conv_igemm2_kernel: the results are bit-identical (tests/test_conv_gpu.py::test_conv1x1_ring_is_bit_identical), so which kernel takes
 // a launch never shows in a frame's result.
@@ -108,26 +108,63 @@ __device__ __forceinline__ void rg_dma8(unsigned lds, int4v rsrc, unsigned soff,
 
 constexpr unsigned RG_OOB = 0x80000000u;
 
+// The bias of a wave's 64 channels through the SCALAR cache (the address is wave-uniform): eight s_load_dwordx8 issued together,
+// one wait.  asm, because the compiler will not prove that the kernel's own stores leave the bias alone and falls back to vector
+// loads - which queue behind the loaders' DMA stream with every consumer waiting (~1-2 us per tile).
+typedef float float8v __attribute__((ext_vector_type(8)));
+struct RgBias { float8v v[8]; };      // v[4 j + q] = channels [32 j + 8 q, +8)
+__device__ __forceinline__ void rg_bias_issue(RgBias& b, const float* p) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    const unsigned long long u = ((unsigned long long)hi << 32) | lo;
+    asm volatile(
+        "s_load_dwordx8 %0, %8, 0x0\n\ts_load_dwordx8 %1, %8, 0x20\n\ts_load_dwordx8 %2, %8, 0x40\n\ts_load_dwordx8 %3, %8, 0x60\n\t"
+        "s_load_dwordx8 %4, %8, 0x80\n\ts_load_dwordx8 %5, %8, 0xa0\n\ts_load_dwordx8 %6, %8, 0xc0\n\ts_load_dwordx8 %7, %8, 0xe0"
+        : "=&s"(b.v[0]), "=&s"(b.v[1]), "=&s"(b.v[2]), "=&s"(b.v[3]), "=&s"(b.v[4]), "=&s"(b.v[5]), "=&s"(b.v[6]), "=&s"(b.v[7])
+        : "s"(u));
+}
+__device__ __forceinline__ void rg_bias_wait(RgBias& b) {      // every later use of b depends on this statement
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+s"(b.v[0]), "+s"(b.v[1]), "+s"(b.v[2]), "+s"(b.v[3]), "+s"(b.v[4]), "+s"(b.v[5]), "+s"(b.v[6]), "+s"(b.v[7]));
+}
+
 // MFMA row i of a 32-channel block <- weight row perm(i): lane half h then holds channels 16 h + e in accumulator register e
 __device__ __forceinline__ int rg_perm(int i) { return ((i >> 2) & 1) * 16 + (i >> 3) * 4 + (i & 3); }
 
+// One K-step of a wave = four MFMA K-steps of 16: the fragments of the first TWO are requested at once (nothing of the step can be read
+// before its barrier), the third / fourth go into the first / second set's registers behind its MFMAs (32 fragment VGPRs: with 64
+// accumulators and the bias in registers the 168-register budget of three waves per SIMD has no room for all four sets).
 template <int TMI>
 __device__ __forceinline__ void rg_compute(float16v (&acc)[2][2], const unsigned char* pa, const unsigned char* pb, int fswa, int fswb,
                                            int fkh) {
-#pragma unroll
-    for (int ks = 0; ks < BK / 16; ++ks) {
+    half8 pf[2][TMI], wf[2][2];
+    auto load = [&](int ks, int buf) {
         const int cha = ((ks * 2 + fkh) ^ fswa) << 4;
         const int chb = ((ks * 2 + fkh) ^ fswb) << 4;
-        half8 pf[TMI], wf[2];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) wf[j] = *reinterpret_cast<const half8*>(pb + j * 32 * ROW_B + chb);
+        for (int j = 0; j < 2; ++j) wf[buf][j] = *reinterpret_cast<const half8*>(pb + j * 32 * ROW_B + chb);
 #pragma unroll
-        for (int i = 0; i < TMI; ++i) pf[i] = *reinterpret_cast<const half8*>(pa + i * 32 * ROW_B + cha);
+        for (int i = 0; i < TMI; ++i) pf[buf][i] = *reinterpret_cast<const half8*>(pa + i * 32 * ROW_B + cha);
+    };
+    auto mma = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < TMI; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[j], pf[i], acc[i][j], 0, 0, 0);
-    }
+            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[buf][j], pf[buf][i], acc[i][j], 0, 0, 0);
+    };
+    // sched_barrier(0): nothing crosses - left alone, the scheduler folds the two sets back into one and every MFMA K-step waits for
+    // its own reads
+    load(0, 0);
+    load(1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(0);
+    load(2, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(1);
+    load(3, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(0);
+    mma(1);
 }
 
 __global__ __launch_bounds__(RG_THREADS) void conv1x1_ring_kernel(RingArgs a) {
@@ -139,13 +176,21 @@ __global__ __launch_bounds__(RG_THREADS) void conv1x1_ring_kernel(RingArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     // ---- this workgroup's run of 32-pixel blocks, as m-tiles of up to four blocks x tiles_n column tiles x K / 64 steps ----
-    const int G = gridDim.x;
-    const int b0 = (int)((long long)blockIdx.x * a.nblk / G), b1 = (int)((long long)(blockIdx.x + 1) * a.nblk / G);
+    // Cout > 256 (tiles_n column tiles): when the grid allows it the column tiles of a run go to tiles_n workgroups of ONE XCD
+    // (blockIdx % 8 is the XCD: workgroups w, w + 8, ... share it) that start together and walk the same pixels in step, so a pixel
+    // line crosses the fabric once and the others hit the XCD's L2 - the run's pixels x K do not fit any cache between two passes.
+    // Otherwise (small grids) one workgroup walks the column tiles of each m-tile one after the other.
+    const bool npar = a.tiles_n > 1 && gridDim.x % (8 * a.tiles_n) == 0;
+    const int G = npar ? gridDim.x / a.tiles_n : gridDim.x;                                   // runs
+    const int run = npar ? (blockIdx.x & 7) + 8 * (blockIdx.x / (8 * a.tiles_n)) : blockIdx.x;
+    const int n0 = npar ? (blockIdx.x >> 3) % a.tiles_n : 0;                                  // first column tile of this workgroup
+    const int nseq = npar ? 1 : a.tiles_n;                                                    // column tiles it walks per m-tile
+    const int b0 = (int)((long long)run * a.nblk / G), b1 = (int)((long long)(run + 1) * a.nblk / G);
     const int nb = b1 - b0;
     if (nb <= 0) return;
     const int nmt = (nb + 3) >> 2;
     const int nk = a.K >> 6;
-    const int S = nmt * a.tiles_n * nk;      // K-steps = barriers, the same number in every wave
+    const int S = nmt * nseq * nk;           // K-steps = barriers, the same number in every wave
 
     if (wave == RG_CONSUMERS) {
         // ================= pixel loader: ring of 4 x [128 px][64 ch], three stages ahead =================
@@ -183,18 +228,19 @@ __global__ __launch_bounds__(RG_THREADS) void conv1x1_ring_kernel(RingArgs a) {
             }
             if (++u_ks == nk) {
                 u_ks = 0;
-                if (++u_n == a.tiles_n) { u_n = 0; ++u_mt; }
+                if (++u_n == nseq) { u_n = 0; ++u_mt; }
             }
         };
         issue(0);
         issue(1);
         issue(2);
-        int st = 3;
+        int st = 3, c_ks = 0;
         for (int s = 0; s < S; ++s) {
             asm volatile("s_waitcnt vmcnt(32)" ::: "memory");     // slab s has landed; slabs s + 1, s + 2 (16 pieces each) may be in flight
             __builtin_amdgcn_s_barrier();
             issue(st);                                             // slab s + 3 into the slot of slab s - 1 (steps beyond S: zeros, no traffic)
             st = (st + 1) & 3;
+            if (++c_ks == nk) { c_ks = 0; __builtin_amdgcn_s_barrier(); }     // the consumers' end-of-tile barrier (see their epilogue)
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // no DMA may outlive the workgroup's LDS allocation
         return;
@@ -211,7 +257,7 @@ __global__ __launch_bounds__(RG_THREADS) void conv1x1_ring_kernel(RingArgs a) {
         const int4v rs = rg_make_rsrc(a.wgt, (unsigned)a.Cout * (unsigned)a.K * 2u);
         int u_ks = 0, u_n = 0, u_mt = 0;
         auto issue = [&](int stage) {
-            const unsigned soff = u_mt < nmt ? (unsigned)(u_n * RG_BN * a.K + u_ks * 64) * 2u : RG_OOB;
+            const unsigned soff = u_mt < nmt ? (unsigned)((n0 + u_n) * RG_BN * a.K + u_ks * 64) * 2u : RG_OOB;
             const unsigned lds = smem_base + RG_BBASE + stage * RG_BSTAGE_B;
             if (!(a.abl & 2)) {
                 rg_dma8(lds, rs, soff, rel[0], rel[1], rel[2], rel[3], rel[4], rel[5], rel[6], rel[7]);
@@ -221,17 +267,18 @@ __global__ __launch_bounds__(RG_THREADS) void conv1x1_ring_kernel(RingArgs a) {
             }
             if (++u_ks == nk) {
                 u_ks = 0;
-                if (++u_n == a.tiles_n) { u_n = 0; ++u_mt; }
+                if (++u_n == nseq) { u_n = 0; ++u_mt; }
             }
         };
         issue(0);
         issue(1);
-        int st = 2;
+        int st = 2, c_ks = 0;
         for (int s = 0; s < S; ++s) {
             asm volatile("s_waitcnt vmcnt(32)" ::: "memory");     // slab s has landed; slab s + 1 (32 pieces) may be in flight
             __builtin_amdgcn_s_barrier();
             issue(st);                                             // slab s + 2 into the slot of slab s - 1
             st = st == 2 ? 0 : st + 1;
+            if (++c_ks == nk) { c_ks = 0; __builtin_amdgcn_s_barrier(); }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         return;
@@ -254,54 +301,70 @@ __global__ __launch_bounds__(RG_THREADS) void conv1x1_ring_kernel(RingArgs a) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    int sa = 0, sb = 0, ks = 0, n = 0, mt = 0;
+    RgBias bs;       // live from the tile's last K-step to its epilogue only (a launch without a bias stays on conv_igemm2: conv2_dispatch)
+    int sa = 0, sb = 0, ks = 0, n = n0, mt = 0;
     for (int s = 0; s < S; ++s) {
         __builtin_amdgcn_s_barrier();
         const int nbt = nb - 4 * mt;                 // pixel blocks of this m-tile (>= 4: a full tile)
         const int mine = nbt - 2 * wm;               // ... of which this wave owns min(2, mine)
         const unsigned char* pa = la + sa * RG_ASTAGE_B;
         const unsigned char* pb = lb + sb * RG_BSTAGE_B;
-        if (a.abl & 4) {
-        } else if (mine >= 2) rg_compute<2>(acc, pa, pb, fswa, fswb, fkh);
-        else if (mine == 1) rg_compute<1>(acc, pa, pb, fswa, fswb, fkh);
-        sa = (sa + 1) & 3;
-        sb = sb == 2 ? 0 : sb + 1;
+        if (ks == nk - 1) rg_bias_issue(bs, a.bias + n * RG_BN + wn * 64);      // in flight under the tile's last K-step
+        // ONE code path: a wave that owns one block of a partial tile multiplies the loader's zeros for the other (a second, 1-block
+        // path makes the accumulators PHI values: 32 v_mov per K-step behind the MFMAs - measured +9 us per launch); a wave that owns
+        // none skips the step, which leaves its SIMD to the other wave: a partial tile costs about half a tile either way
+        if (mine >= 1 && !(a.abl & 4)) rg_compute<2>(acc, pa, pb, fswa, fswb, fkh);
         if (++ks == nk) {
-            // ---- tile epilogue: + bias, ReLU, fp16; a lane stores 32 contiguous bytes per pixel and 32-channel block ----
+            // ---- tile epilogue: + bias, ReLU, fp16, WHOLE 128-byte lines.  Stores straight from the accumulator layout are 16-byte
+            // pieces 512 B apart - 64 write requests per instruction, measured at 17 of the launch's 78 us (profiles/r05_ring_abl.txt).
+            // After the end-of-tile barrier nobody reads the weight slot of the tile's last K-step any more, and its loader refills it
+            // only behind the NEXT step's barrier, which the consumers reach after this epilogue: each wave transposes its 32 pixels x
+            // 64 channels through a private 4 KiB patch of that slot (chunk c of row r in slot c ^ (r & 7)) and stores 8 whole lines
+            // per instruction.
+            __builtin_amdgcn_s_barrier();
+            unsigned char* patch = smem + RG_BBASE + sb * RG_BSTAGE_B + wave * 4096;
             const int mrow0 = (b0 + 4 * mt) * 32;
             int vrows = (nbt < 4 ? nbt : 4) * 32;
             vrows = vrows < a.M - mrow0 ? vrows : a.M - mrow0;
+            if (a.abl & 8) vrows = 0;
+            const int chw = n * RG_BN + wn * 64;                    // this wave's first output channel
+            rg_bias_wait(bs);
+            const int rr = lane >> 3, rp = lane & 7;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int ch = n * RG_BN + wn * 64 + j * 32 + fkh * 16;
-                float bv[16];
+            for (int i = 0; i < 2; ++i) {
 #pragma unroll
-                for (int e4 = 0; e4 < 4; ++e4) {
-                    const float4v b = a.bias ? *reinterpret_cast<const float4v*>(a.bias + ch + e4 * 4) : float4v{0.f, 0.f, 0.f, 0.f};
-                    bv[e4 * 4 + 0] = b[0]; bv[e4 * 4 + 1] = b[1]; bv[e4 * 4 + 2] = b[2]; bv[e4 * 4 + 3] = b[3];
-                }
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const int row = wm * 64 + i * 32 + frow;
+                for (int j = 0; j < 2; ++j) {
                     half8 h0, h1;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        float x0 = acc[i][j][e] + bv[e], x1 = acc[i][j][e + 8] + bv[e + 8];
+                        const float b0 = fkh ? bs.v[j * 4 + 2][e] : bs.v[j * 4 + 0][e];
+                        const float b1 = fkh ? bs.v[j * 4 + 3][e] : bs.v[j * 4 + 1][e];
+                        float x0 = acc[i][j][e] + b0, x1 = acc[i][j][e + 8] + b1;
                         if (a.relu) { x0 = pe::relu_nan(x0); x1 = pe::relu_nan(x1); }
                         h0[e] = (_Float16)x0;
                         h1[e] = (_Float16)x1;
                     }
-                    // rows beyond this tile's pixels (another workgroup's, or beyond M) get an out-of-range offset: the store is dropped
-                    const unsigned off = (row < vrows && !(a.abl & 8)) ? (unsigned)(((mrow0 + row) * a.out_stride + ch) * 2) : RG_OOB;
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4v, h0), rout, off, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4v, h1), rout, off, 16, 0);
+                    const int c0 = j * 4 + fkh * 2;                 // 16-byte chunk of this lane's first 8 channels within the wave's 128 B
+                    *reinterpret_cast<half8*>(patch + frow * 128 + ((c0 ^ (frow & 7)) << 4)) = h0;
+                    *reinterpret_cast<half8*>(patch + frow * 128 + (((c0 + 1) ^ (frow & 7)) << 4)) = h1;
 #pragma unroll
                     for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
                 }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int r = t * 8 + rr;                       // row of the patch; slot rp holds chunk rp ^ (r & 7) = rp ^ (rr & 7)
+                    const half8 v = *reinterpret_cast<const half8*>(patch + r * 128 + (rp << 4));
+                    const int row = wm * 64 + i * 32 + r;
+                    // rows beyond this tile's pixels (another workgroup's, or beyond M) get an out-of-range offset: the store is dropped
+                    const unsigned off = row < vrows ? (unsigned)(((mrow0 + row) * a.out_stride + chw + ((rp ^ (rr & 7)) << 3)) * 2) : RG_OOB;
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4v, v), rout, off, 0, 0);
+                }
             }
             ks = 0;
-            if (++n == a.tiles_n) { n = 0; ++mt; }
+            if (++n == n0 + nseq) { n = n0; ++mt; }
         }
+        sa = (sa + 1) & 3;
+        sb = sb == 2 ? 0 : sb + 1;
     }
 }
 
@@ -326,7 +389,9 @@ int conv1x1_ring_launch(const void* in, const void* wgt, const float* bias, void
     a.tiles_n = Cout / RG_BN;
     a.abl = g_ring_abl.load(std::memory_order_relaxed);
     const int wgs = g_ring_wgs.load(std::memory_order_relaxed);
-    const int grid = a.nblk < wgs ? a.nblk : wgs;
+    // Cout > 256: tiles_n workgroups per run when every run still has at least one m-tile's worth of blocks
+    int grid = a.nblk < wgs ? a.nblk : wgs;
+    if (a.tiles_n > 1 && wgs % (8 * a.tiles_n) == 0 && a.nblk >= wgs / a.tiles_n) grid = wgs;
     PE_ENSURE_LDS(conv1x1_ring_kernel, (size_t)RG_LDS, "pe_conv2d_nhwc_f16(1x1 ring)");
     hipLaunchKernelGGL(conv1x1_ring_kernel, dim3(grid), dim3(RG_THREADS), (size_t)RG_LDS, st, a);
     PE_CHECK_LAUNCH("pe_conv2d_nhwc_f16(1x1 ring)");

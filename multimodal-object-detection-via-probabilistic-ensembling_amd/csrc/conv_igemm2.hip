@@ -463,8 +463,9 @@ namespace pe {
 bool conv1x1_ring_eligible(int M, int K, int Cout, int cout_store, int out_stride);
 int conv1x1_ring_launch(const void* in, const void* wgt, const float* bias, void* out, int M, int K, int Cout, int out_stride, int relu,
                         hipStream_t st);
-std::atomic<int> g_conv_tile256{9};   // bit 0: 256-row tiles for big 3x3 launches, bit 1: for big 1x1 launches, bit 2: two-stage 1x1 pipeline,
-                                      // bit 3: 256x256 two-stage kernel for long-K GEMMs, bit 4: ... for every eligible launch
+std::atomic<int> g_conv_tile256{73};  // bit 0: 256-row tiles for big 3x3 launches, bit 1: for big 1x1 launches, bit 2: two-stage 1x1 pipeline,
+                                      // bit 3: 256x256 two-stage kernel for long-K GEMMs, bit 4: ... for every eligible launch,
+                                      // bit 5 / 6: the persistent loader / consumer 1x1 kernel for res4 conv1 / for every eligible launch
 std::atomic<int> g_conv3x3_reuse{1};  // 0: the generic per-tap 3x3 kernel instead of the kw-reuse one (A/B measurements)
 // called from pe_conv2d_nhwc_f16 (conv_igemm.hip) for the 1x1 / 3x3 cases
 int conv2_dispatch(const void* in, const void* wgt, const float* bias, const void* res, void* out, int N, int H, int W,
@@ -479,7 +480,7 @@ int conv2_dispatch(const void* in, const void* wgt, const float* bias, const voi
     const bool narrow = Cout <= 64;
     // persistent loader / consumer 1x1 kernel (csrc/conv1x1_ring.hip; bit-identical results): policy bit 5 = the long-K, 256-output
     // layers (res4 conv1), bit 6 = every eligible launch.  Chosen by channel counts only, never by the batch.
-    if ((policy & 96) && !mode3x3 && stride == 1 && !res_mode && !out_f32 && K >= 512 &&
+    if ((policy & 96) && !mode3x3 && stride == 1 && !res_mode && !out_f32 && bias && K >= 512 &&
         ((policy & 64) || (K >= 1024 && Cout == 256)) && conv1x1_ring_eligible(M, K, Cout, cout_store, out_stride))
         return conv1x1_ring_launch(in, wgt, bias, out, M, K, Cout, out_stride, relu, st);
     // 256 x 256 two-stage kernel: fp16 output, whole 256-channel tiles, a grid that fills the 256 CUs

@@ -5,7 +5,7 @@
 extern "C" {
 #endif
 /* Kernel-selection policy of pe_conv2d_nhwc_f16 (process-global, relaxed atomics; affects launches issued afterwards).
- *   tile_bits (default 9 = 1|8):  1: 256-row block tiles (8 waves) for 3x3 launches with >= 512 such tiles   2: the same for 1x1
+ *   tile_bits (default 73 = 1|8|64):  1: 256-row block tiles (8 waves) for 3x3 launches with >= 512 such tiles   2: the same for 1x1
  *                                 4: two-stage pipeline in the generic 1x1 kernel   8: 256x256 two-stage kernel for long-K GEMMs
  *                                16: 256x256 kernel for every eligible launch
  *                                32: persistent loader / consumer 1x1 kernel (csrc/conv1x1_ring.hip) for K >= 1024, Cout == 256 (res4 conv1)

@@ -29,7 +29,8 @@ def main():
     print("# bit comparison: ring (policy 9 + 64) vs conv_igemm2 (policy 9)")
     for (N, H, W, Cin, Cout, relu, bias) in [(32, 50, 64, 1024, 256, 1, 1), (3, 50, 64, 1024, 256, 1, 1), (1, 13, 16, 2048, 256, 0, 1),
                                              (2, 25, 32, 2048, 512, 1, 0), (1000, 1, 1, 1024, 1024, 1, 1), (1, 7, 9, 512, 256, 1, 1),
-                                             (16, 50, 64, 1024, 256, 1, 1), (5, 1, 1, 1024, 256, 0, 1)]:
+                                             (16, 50, 64, 1024, 256, 1, 1), (5, 1, 1, 1024, 256, 0, 1), (32000, 1, 1, 1024, 1024, 1, 1),
+                                             (4000, 1, 1, 12544, 1024, 1, 1), (32, 25, 32, 2048, 512, 1, 1)]:
         x = torch.randn(N, H, W, Cin, device="cuda").half().relu()
         w = (torch.randn(Cout, 1, 1, Cin, device="cuda") / Cin ** 0.5).half()
         b = torch.randn(Cout, device="cuda") if bias else None
@@ -44,7 +45,7 @@ def main():
         print(f"N{N} {H}x{W} {Cin}->{Cout} relu{relu} bias{bias}: identical={same} max|d|={md:.3g} nan={int(torch.isnan(out).sum())}", flush=True)
     print("# timing (ms per launch; GB/s = algorithmic bytes)")
     for (N, H, W, Cin, Cout) in [(32, 50, 64, 1024, 256), (16, 50, 64, 1024, 256), (32, 25, 32, 2048, 512), (32, 25, 32, 2048, 256),
-                                 (32000, 1, 1, 1024, 1024), (32, 100, 128, 512, 256), (32, 200, 256, 256, 256)]:
+                                 (32000, 1, 1, 1024, 1024), (32, 100, 128, 512, 256), (32000, 1, 1, 12544, 1024)]:
         x = torch.randn(N, H, W, Cin, device="cuda").half().relu()
         w = (torch.randn(Cout, 1, 1, Cin, device="cuda") / Cin ** 0.5).half()
         b = torch.randn(Cout, device="cuda")
@@ -52,7 +53,7 @@ def main():
         M = N * H * W
         nbytes = (M * Cin + Cout * Cin + M * Cout) * 2
         row = []
-        for name, pol, wgs in [("igemm2", 9, 256), ("ring256", 73, 256), ("ring248", 73, 248), ("ring128", 73, 128), ("ring512", 73, 512), ("igemm2", 9, 256), ("ring256", 73, 256)]:
+        for name, pol, wgs in [("r04", 9, 256), ("ring256", 73, 256), ("ring224", 73, 224), ("ring128", 73, 128), ("r04", 9, 256), ("ring256", 73, 256)]:
             hooks.pe_test_set_conv_policy(pol, 1)
             hooks.pe_test_set_ring_wgs(wgs)
             ms = timeit(lambda: L.conv2d_nhwc(x, w, b, kernel=1, relu=True, out=out))

@@ -328,22 +328,6 @@ def test_transform_gen_and_host_resize_rules():
     assert t.apply_image(img).dtype == np.uint8 and M.ResizeTransform(4, 16, 4, 32).apply_image(ramp).shape == (4, 32, 4)
 
 
-def test_log_average_miss_rate_properties():
-    """KAIST metric (parity unpinned - the reference's evaluator is missing from its tree): known-answer cases."""
-    gt = [[(10, 10, 20, 40, 0), (100, 50, 20, 40, 0)], [(30, 30, 25, 50, 0)], [(5, 5, 10, 20, 1)]]
-    perfect = [[(10, 10, 20, 40, 0.9), (100, 50, 20, 40, 0.8)], [(30, 30, 25, 50, 0.95)], [(5, 5, 10, 20, 0.99)]]
-    lamr, mr, pts = evaluation.log_average_miss_rate(gt, perfect)
-    assert lamr == pytest.approx(1e-10) and np.all(mr == 0)          # everything found, the ignore match is free
-    none = [[], [], []]
-    assert evaluation.log_average_miss_rate(gt, none)[0] == pytest.approx(1.0)
-    # one miss out of three and one high-scoring false positive: MR = 1/3 once FPPI >= 1/3, 1.0 below... the FP
-    # outranks everything, so at FPPI < 1/3 nothing is counted yet
-    dets = [[(10, 10, 20, 40, 0.9)], [(30, 30, 25, 50, 0.8), (200, 200, 20, 40, 0.99)], []]
-    lamr2, mr2, pts2 = evaluation.log_average_miss_rate(gt, dets)
-    assert np.all(mr2[pts2 < 1 / 3] == 1.0) and np.allclose(mr2[pts2 >= 1 / 3], 1 / 3)
-    assert 1 / 3 < lamr2 < 1.0
-
-
 def test_bench_board_power_sampler_is_best_effort(tmp_path, monkeypatch):
     """bench.py's `power` object: a helper process polls rocm-smi during the timed region.  With a rocm-smi that answers, samples
     inside the window are summarised (median board power, cap, shader clock, joules per unit) and the helper's process group is

@@ -100,7 +100,7 @@ def test_conv_big_tile_kernel(L, case, policy):
         out = L.conv2d_nhwc(nhwc(x), w.permute(0, 2, 3, 1).contiguous(), b, kernel=k, stride=s, relu=relu, residual=res, residual_mode=res_mode)
         torch.cuda.synchronize()
     finally:
-        hooks.pe_test_set_conv_policy(9, 1)
+        hooks.pe_test_set_conv_policy(L.DEFAULT_CONV_POLICY, 1)
     torch.testing.assert_close(out.permute(0, 3, 1, 2).float(), ref, rtol=4e-3, atol=4e-3)
 
 
@@ -123,7 +123,7 @@ def test_conv3x3_weight_double_buffered_kernel(L, case):
         out = L.conv2d_nhwc(nhwc(x), w.permute(0, 2, 3, 1).contiguous(), b, kernel=k, stride=s, relu=relu)
         torch.cuda.synchronize()
     finally:
-        hooks.pe_test_set_conv_policy(9, 1)
+        hooks.pe_test_set_conv_policy(L.DEFAULT_CONV_POLICY, 1)
     torch.testing.assert_close(out.permute(0, 3, 1, 2).float(), ref, rtol=4e-3, atol=4e-3)
 
 
