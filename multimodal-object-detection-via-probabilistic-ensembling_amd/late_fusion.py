@@ -68,7 +68,7 @@ def late_fusion(dets, method, device="cuda"):
     (boxes float64 [m,4] | None, scores f32, classes f32); None = skipped image (no detector fired).
     Case split of demo_probEn.py:237-267: 0 detectors -> skip, 1 -> passthrough, >= 2 -> fusion of the
     non-empty lists in order.  All images needing fusion go through ONE batched launch."""
-    n_img = len(dets[-1]["image"]) if len(dets) > 1 else len(dets[0]["image"])
+    n_img = len(dets[1]["image"]) if len(dets) > 1 else len(dets[0]["image"])      # the reference loops over det_2's images (:205)
     results = [None] * n_img
     batch, where = [], []
     for i in range(n_img):
@@ -100,9 +100,13 @@ def late_fusion(dets, method, device="cuda"):
     return results
 
 
-def apply_late_fusion_and_evaluate(cfg, evaluator, det_1, det_2, method, det_3="", image_hw=None, device="cuda"):
+def apply_late_fusion_and_evaluate(cfg, evaluator, det_1, det_2, method, det_3="", image_hw=None, device="cuda",
+                                   img_folder="../../../Datasets/FLIR/val/thermal_8_bit/"):
     """Same call as the reference (demo_probEn.py:198).  `image_hw`: {image_id: (H, W)} from the dataset
-    json (the reference re-reads every thermal JPEG just for its shape); default 512 x 640 (FLIR)."""
+    json (the reference re-reads every thermal JPEG just for its shape); default 512 x 640 (FLIR).
+    `img_folder`: the prefix the reference hard-codes into the `file_name` it hands to the evaluator (:200,271).
+    What the evaluator receives per image is pinned by tests/golden/p5_cases.json (the reference's function run with a recording
+    evaluator): tests/test_pipeline_gpu.py::test_late_fusion_driver_reproduces_the_references_records."""
     evaluator.reset()
     print("Method: ", method)
     start = time.time()
@@ -118,7 +122,7 @@ def apply_late_fusion_and_evaluate(cfg, evaluator, det_1, det_2, method, det_3="
         inst.pred_boxes = Boxes(torch.as_tensor(np.asarray(boxes), dtype=torch.float32).reshape(-1, 4))
         inst.scores = scores
         inst.pred_classes = classes
-        name = det_1["image"][i].split(".")[0] + ".jpeg"
+        name = img_folder + det_1["image"][i].split(".")[0] + ".jpeg"
         evaluator.process([{"file_name": name, "height": H, "width": W, "image_id": iid}], [{"instances": inst}])
     print("Average time:", (time.time() - start) / max(len(det_2["image"]), 1))
     return evaluator.evaluate()

@@ -9,9 +9,12 @@ Restates the arithmetic of the reference's per-image fusion:
   demo/FLIR/demo_probEn.py:20-22   avg_bbox_fusion
   demo/FLIR/demo_probEn.py:44-71   nms_1               (the ('max','argmax') route)
   demo/FLIR/demo_probEn.py:189-196 fusion              (dispatch)
+  demo/FLIR/demo_probEn.py:198-298 apply_late_fusion_and_evaluate (per-image driver: which lists are fused, what the evaluator gets)
 
 Pinned by tests/golden/proben_*.npz, generated in the build container by
-running the reference functions themselves (tests/golden/gen_proben.py).
+running the reference functions themselves (tests/golden/gen_proben.py); the
+driver by tests/golden/p5_cases.json (gen_p5.py: the reference's function run
+on three prediction dicts with a recording evaluator).
 
 Tie rule (reference: ``scores.argsort()[::-1]``, an unstable sort whose tie
 order depends on the NumPy build): score descending, then ORIGINAL INDEX
@@ -168,3 +171,32 @@ def fusion(method, info_1, info_2, info_3=""):
         return b32[keep], s32[keep], c32[keep]
     keep, s, b, c = nms_bayesian(boxes, scores, classes, probs, variances, 0.5, method[0], method[1])
     return b, s.astype(np.float32), c.astype(np.float32)
+
+
+def late_fusion_rows(det_1, det_2, method, det_3="", img_folder="../../../Datasets/FLIR/val/thermal_8_bit/", image_hw=(512, 640)):
+    """The per-image driver (demo_probEn.py:198-298) up to `evaluator.process`: one record per image that reaches the evaluator.
+      * the loop runs over det_2's images (:205); a detector "fired" when its box list is non-empty (:224,236);
+      * nobody fired -> the image is skipped (:239-240); one fired -> its list passes through unchanged, detector 1 first, then 2,
+        then 3 (:242-254); two of three -> fusion of the two non-empty lists in detector order (:256-266); all -> fusion of all (:268-269);
+      * file_name = img_folder + detector 1's image name up to its first '.' + '.jpeg' (:271); image_id is detector 2's (:283);
+        height / width come from the image file (:272-273; FLIR thermal frames are 512 x 640);
+      * boxes reach `Boxes` as float64 and are stored as float32 (structures/boxes.py:147-149), scores / classes as float32
+        (`torch.Tensor(list)`, :246-247; the fused route's are float32 already)."""
+    rows = []
+    dets = [det_1, det_2] + ([det_3] if det_3 else [])
+    for i in range(len(det_2["image"])):
+        infos = [{"img_name": d["image"][i], "bbox": d["boxes"][i], "score": d["scores"][i], "class": d["classes"][i],
+                  "prob": d["probs"][i], "vars": d["vars"][i]} for d in dets]
+        live = [x for x in infos if len(x["bbox"]) > 0]
+        if not live:
+            continue
+        if len(live) == 1:
+            b = np.asarray(live[0]["bbox"], dtype=np.float64)
+            sc = np.asarray(live[0]["score"], dtype=np.float32)
+            c = np.asarray(live[0]["class"], dtype=np.float32)
+        else:
+            b, sc, c = fusion(method, *live)
+        rows.append({"file_name": img_folder + det_1["image"][i].split(".")[0] + ".jpeg", "image_id": det_2["image_id"][i],
+                     "height": image_hw[0], "width": image_hw[1], "boxes": np.asarray(b, dtype=np.float64).astype(np.float32).reshape(-1, 4),
+                     "scores": np.asarray(sc, dtype=np.float32), "classes": np.asarray(c, dtype=np.float32)})
+    return rows

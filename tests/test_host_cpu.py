@@ -195,6 +195,30 @@ def test_j1_prediction_schema(tmp_path):
     late_fusion.write_j1(str(p), pred)
     assert late_fusion.read_j1(str(p)) == json.loads(json.dumps(pred))
 
+def test_j1_writer_reproduces_the_references_file_byte_for_byte(tmp_path, golden_dir):
+    """predictions_to_j1 + write_j1 against tests/golden/j1_case.json = the prediction file the REFERENCE's writer statements
+    (demo/FLIR/demo_FLIR_save_predictions.py:133-176, executed on stub predictor outputs by tests/golden/gen_j1.py) produce for the
+    same detections: key order, indent, the float repr of float32 values widened by `.tolist()`, classes > 2 dropped, empty images."""
+    z = json.load(open(os.path.join(golden_dir, "j1_case.json")))
+    K = z["K"]
+    f32 = lambda u, *shape: torch.from_numpy(np.asarray(u, dtype=np.uint32).view(np.float32).reshape(*shape).copy())  # noqa: E731
+    insts = []
+    for fr in z["frames"]:
+        n = fr["n"]
+        inst = Instances((512, 640))
+        inst.pred_boxes = Boxes(f32(fr["boxes_u32"], n, 4))
+        inst.scores = f32(fr["scores_u32"], n)
+        inst.pred_classes = torch.tensor(fr["classes"], dtype=torch.int64)
+        inst.class_logits = f32(fr["logits_u32"], n, K + 1)
+        inst.prob_score = f32(fr["probs_u32"], n, K)
+        inst.vars = f32(fr["vars_u32"], n, 1)
+        insts.append(inst)
+    pred = late_fusion.predictions_to_j1(z["files_names"], z["image_ids"], insts)
+    p = tmp_path / "val_thermal_only_predictions.json"
+    late_fusion.write_j1(str(p), pred)
+    assert p.read_text() == z["text"]
+    assert any(c > 2 for fr in z["frames"] for c in fr["classes"]) and any(fr["n"] == 0 for fr in z["frames"])   # the fixture covers both
+
 
 def test_model_zoo_pickle_reader_and_rgb_only_cfg(tmp_path, monkeypatch):
     """checkpoint/detection_checkpoint.py:27-45: a detectron2 model-zoo `.pkl` ({"model": ndarrays, "__author__"}) loads into the same

@@ -58,3 +58,26 @@ def test_binary_bayesian_fusion(cases):
         off += m
         got, _ = O.fuse_score("probEn_binary", np.zeros((m, 1)), v, 0)
         assert got == pytest.approx(want, rel=1e-14)
+
+
+def test_oracle_driver_reproduces_the_references_records(golden_dir):
+    """oracle.proben.late_fusion_rows against tests/golden/p5_cases.json = what the REFERENCE's apply_late_fusion_and_evaluate
+    (demo_probEn.py:198-298, executed by tests/golden/gen_p5.py with a recording evaluator) hands to `evaluator.process`: which images are
+    skipped, passed through or fused (2 and 3 detectors, every firing pattern), file_name from detector 1's name with '.jpeg', image_id
+    from detector 2, float32 boxes / scores / classes - for the 11 (score, box) combinations the reference runs without torchvision."""
+    import json
+    from oracle import proben as O
+    z = json.load(open(os.path.join(golden_dir, "p5_cases.json")))
+    assert len(z["runs"]) == 22
+    for key, want in z["runs"].items():
+        sm, bm, kdet = key.rsplit("_", 2)
+        got = O.late_fusion_rows(z["det_1"], z["det_2"], [sm, bm], det_3=z["det_3"] if kdet == "3" else "")
+        assert [r["file_name"] for r in got] == [r["file_name"] for r in want], key
+        assert [r["image_id"] for r in got] == [r["image_id"] for r in want] and all(r["height"] == 512 and r["width"] == 640 for r in want)
+        for g, w in zip(got, want):
+            assert w["boxes_dtype"] == "torch.float32" and w["scores_dtype"] == "torch.float32" and w["classes_dtype"] == "torch.float32"
+            np.testing.assert_array_equal(g["classes"], np.asarray(w["classes"], np.float32))
+            np.testing.assert_allclose(g["scores"], np.asarray(w["scores"], np.float32), rtol=1e-6, atol=0)
+            np.testing.assert_allclose(g["boxes"], np.asarray(w["boxes"], np.float32).reshape(-1, 4), rtol=1e-6, atol=1e-5)
+    # the firing patterns of the fixture cover every branch of the driver's case split
+    assert {tuple(f) for f in z["fire"]} == {(a, b, c) for a in (0, 1) for b in (0, 1) for c in (0, 1)}

@@ -352,3 +352,43 @@ def test_config3_three_detector_pipeline_full_size():
     rows = LF.fused_rows_device(fused, list(range(100, 100 + B))).cpu().numpy()
     assert rows.shape[1] == 7 and len(rows) <= int(cnt.sum()) and set(rows[:, 6].astype(int)) <= {0, 1, 2}
     assert np.all(rows[:, 3] > 0) and np.all(rows[:, 4] > 0) and np.all((rows[:, 5] > 0) & (rows[:, 5] <= 1))
+
+
+def test_late_fusion_driver_reproduces_the_references_records(golden_dir):
+    """proben_amd.late_fusion.apply_late_fusion_and_evaluate (same call as demo_probEn.py:198; the fused images go through ONE batched
+    launch of the ProbEn kernel) against tests/golden/p5_cases.json - the records the REFERENCE's function handed to its evaluator when
+    tests/golden/gen_p5.py ran it on the same three prediction dicts: which images are skipped / passed through / fused (2 and 3
+    detectors, every firing pattern), file_name, image_id (detector 2's), height / width, float32 boxes / scores / classes in the
+    reference's row order, for the 11 (score, box) combinations."""
+    import json
+    import os
+    import proben_amd  # noqa: F401
+    from proben_amd import late_fusion as LF
+
+    class Recorder:
+        def reset(self):
+            self.rows = []
+
+        def process(self, inputs, outputs):
+            for i, o in zip(inputs, outputs):
+                inst = o["instances"]
+                assert inst.pred_boxes.tensor.dtype == torch.float32 and inst.scores.dtype == torch.float32 and inst.pred_classes.dtype == torch.float32
+                self.rows.append(dict(i, boxes=inst.pred_boxes.tensor.cpu().numpy(), scores=inst.scores.cpu().numpy(), classes=inst.pred_classes.cpu().numpy(),
+                                      image_size=tuple(inst.image_size)))
+
+        def evaluate(self):
+            return {"recorded": len(self.rows)}
+
+    z = json.load(open(os.path.join(golden_dir, "p5_cases.json")))
+    assert len(z["runs"]) == 22
+    for key, want in z["runs"].items():
+        sm, bm, kdet = key.rsplit("_", 2)
+        rec = Recorder()
+        res = LF.apply_late_fusion_and_evaluate(None, rec, z["det_1"], z["det_2"], [sm, bm], det_3=z["det_3"] if kdet == "3" else "")
+        assert res == {"recorded": len(want)}, key
+        for g, w in zip(rec.rows, want):
+            assert (g["file_name"], g["image_id"], g["height"], g["width"]) == (w["file_name"], w["image_id"], w["height"], w["width"]), key
+            assert g["image_size"] == (w["height"], w["width"])
+            np.testing.assert_array_equal(g["classes"], np.asarray(w["classes"], np.float32))
+            np.testing.assert_allclose(g["scores"], np.asarray(w["scores"], np.float32), rtol=1e-6, atol=0)
+            np.testing.assert_allclose(g["boxes"], np.asarray(w["boxes"], np.float32).reshape(-1, 4), rtol=1e-6, atol=1e-5)
