@@ -66,14 +66,13 @@ def parse(argv=None):
     ap.add_argument("--no-tail-fusion", action="store_true", help="A/B: run conv2 and conv3 of the res4 bottlenecks as two launches")
     ap.add_argument("--no-res2-fusion", action="store_true", help="A/B: run res2 as separate conv launches instead of the fused 64-wide chain")
     ap.add_argument("--serial-detectors", action="store_true", help="run the detectors back to back on one stream")
-    ap.add_argument("--wd9-tail-wgs", type=int, default=0, help="A/B: workgroups of the persistent fused-tail kernel (0 = the library's default)")
     ap.add_argument("--wd9-wgs", type=int, default=0, help="A/B: workgroups of the persistent pure 3x3 kernel (0 = the library's default)")
     ap.add_argument("--no-power", action="store_true", help="do not poll rocm-smi for board power during the timed region")
     ap.add_argument("--conv-policy", type=int, default=-1, help="A/B: tile_bits of pe_test_set_conv_policy (csrc/test_hooks.h; default 73)")
     ap.add_argument("--roi-sort", type=int, default=1, help="0: ROIAlign takes the proposals in RPN order (A/B; identical results)")
     ap.add_argument("--wd9-mode", type=int, default=-1,
                     help="A/B (csrc/test_hooks.h): 0 = two-wave weights-direct kernels only (csrc/conv_wd.h), 1 = persistent one-wave-per-SIMD "
-                         "kernel for the pure 3x3 launches, 4 = for the fused res4 tail, 5 = both; -1 = the library's default")
+                         "kernel for the pure 3x3 launches, 8 = for the fused RPN head, 9 = both; -1 = the library's default (9)")
     ap.add_argument("--stagger", type=int, default=3,
                     help="N > 0 (default 3, two-detector configs): throughput mode of the pipeline - detector 2 trails detector 1 by its "
                          "res<N> stage and batches follow each other without a device-wide wait (all K timed steps still complete "
@@ -201,10 +200,16 @@ def roofline_leg(step, layers_path="", reps=10):
         e1.record()
         torch.cuda.synchronize()
         timing[key] = e0.elapsed_time(e1) / reps * 1e-3
+    def label(r):
+        """bench label of a launch: the kernel name, with the backbone's own 3x3 launches (res3: 128 -> 128, res5: 512 -> 512) told apart
+        from the FPN / RPN 3x3 launches that run on the same kernels"""
+        sh = r["shape"]
+        tag = " @res3" if "Cin128 Cout128 k3" in sh else " @res5" if "Cin512 Cout512 k3" in sh else " @box_head" if " 1x1 Cin" in sh else ""
+        return r["variant"] + tag
     agg, rows = {}, {}
     for r in rec:
         key = (r["variant"], r["shape"])
-        a = agg.setdefault(r["variant"], [0, 0.0, 0.0, 0.0])
+        a = agg.setdefault(label(r), [0, 0.0, 0.0, 0.0])
         a[0] += 1
         a[1] += r["flops"]
         a[2] += timing[key]
@@ -228,61 +233,113 @@ def roofline_leg(step, layers_path="", reps=10):
                 "launches_per_step": n, "avg_launch_ms": round(t / n * 1e3, 4), "gflop_per_launch": round(fl / n / 1e9, 2),
                 "algorithmic_mbytes_per_launch": round(by / n / 1e6, 1), "flop_per_byte": round(fl / by, 1),
                 "tflops": round(tf, 1), "algorithmic_gbs": round(gbs, 1)}
-    # HBM traffic per launch from the PMC counters: measured by separate `rocprofv3 --pmc` passes (they cannot run
-    # inside this process); profiles/*_pmc_traffic.json holds the last committed measurement per kernel name
-    traffic, traffic_src = {}, ""
+    # HBM traffic per launch from the PMC counters and the in-network launch durations of rocprofv3: measured by separate
+    # `rocprofv3` runs (they cannot run inside this process; scripts/collect_profiles.sh) and committed under profiles/.  ONE round's
+    # record is used: profiles/current_pmc_traffic.json if present, else the highest round's `rNN_pmc_traffic.json` (the round's FINAL
+    # record - mid-round files like `rNN_<tag>_pmc_traffic.json` are never picked), with the `rNN_kernel_stats.csv` of the same round.
+    import csv
+    import re
+    prof = os.path.join(ROOT, "profiles")
+    traffic, traffic_src, rocprof, rocprof_src = {}, "", {}, ""
     try:
-        import glob
-        for pth in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json"))):
-            for k, v in json.load(open(pth))["kernels"].items():
-                traffic[k.replace(" ", "")] = (v, os.path.basename(pth))
+        cur = os.path.join(prof, "current_pmc_traffic.json")
+        cands = [f for f in os.listdir(prof) if re.fullmatch(r"r\d+_pmc_traffic\.json", f)]
+        pick = cur if os.path.exists(cur) else (os.path.join(prof, max(cands, key=lambda f: int(f[1:].split("_")[0]))) if cands else "")
+        if pick:
+            traffic_src = os.path.basename(pick)
+            traffic = {k.replace(" ", ""): v for k, v in json.load(open(pick))["kernels"].items()}
+            m = re.match(r"(r\d+)_", traffic_src)
+            stats = os.path.join(prof, (m.group(1) if m else "current") + "_kernel_stats.csv")
+            if os.path.exists(stats):
+                rocprof_src = os.path.basename(stats)
+                for row in csv.DictReader(open(stats)):
+                    rocprof[row["Name"].replace(" ", "").replace("wd::", "").replace("wd9::", "")] = (int(row["Calls"]), float(row["TotalDurationNs"]))
     except Exception:
-        traffic = {}
+        traffic, rocprof = {}, {}
 
-    def find_traffic(kernel):
-        """exact kernel name, else every instantiation of the same kernel template in the newest profile (the bench table groups the
-        pure wd9 launches of all image widths under one label; rocprof names them per template argument): launch-weighted mean"""
-        hit = traffic.get(kernel.replace(" ", ""))
-        if hit:
-            return hit
+    def same_template(table, kernel):
+        """entries of `table` for this bench label: the exact rocprof name, else every instantiation of the same kernel template (the bench
+        groups the wd9 launches of all image widths under one label; rocprof names them per template argument; kernels in an anonymous
+        namespace appear mangled)"""
+        kernel = kernel.split(" @")[0]
+        key = kernel.replace(" ", "")
+        if key in table:
+            return [table[key]]
         base = kernel.split("<")[0]
-        same = [(v, src) for k, (v, src) in traffic.items() if k.split("<")[0].split("::")[-1] == base]
-        if not same:
-            return None
-        newest = max(src for _, src in same)
-        same = [v for v, src in same if src == newest]
-        n = sum(v.get("launches", 1) for v in same)
-        return {"hbm_mb_per_launch": round(sum(v["hbm_mb_per_launch"] * v.get("launches", 1) for v in same) / n, 1)}, newest
+        return [v for k, v in table.items() if k.split("<")[0].split("::")[-1] == base or (base + "E") in k or k.split("(")[0].endswith(base)]
 
-    def with_traffic(d):
-        hit = find_traffic(d["kernel"])
-        if hit:
-            v, src = hit
-            d["traffic"] = round(v["hbm_mb_per_launch"] * 1e6)   # HBM bytes per launch (compare: algorithmic_mbytes_per_launch)
-            d["traffic_detail"] = {"hbm_mbytes_per_launch": v["hbm_mb_per_launch"], "unit": "MB",
-                                   "source": f"rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE, separate passes, profiles/{src}"}
+    def with_traffic(d, kernels=None):
+        """adds the counter traffic per launch and rocprof's in-network average duration (launch-weighted over the label's kernels)"""
+        names = kernels or [d["kernel"]]
+        tv = [v for n in names for v in same_template(traffic, n)]
+        if tv:
+            n = sum(v.get("launches", 1) for v in tv)
+            mb = round(sum(v["hbm_mb_per_launch"] * v.get("launches", 1) for v in tv) / n, 1)
+            d["traffic"] = round(mb * 1e6)                        # HBM bytes per launch (compare: algorithmic_mbytes_per_launch)
+            d["traffic_detail"] = {"hbm_mbytes_per_launch": mb, "unit": "MB", "vs_algorithmic": round(mb / d["algorithmic_mbytes_per_launch"], 3),
+                                   "source": f"rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE, separate passes, profiles/{traffic_src}"}
+        rv = [v for n in names for v in same_template(rocprof, n)]
+        if rv:
+            calls, total = sum(v[0] for v in rv), sum(v[1] for v in rv)
+            avg = total / calls * 1e-9
+            work = d["gflop_per_launch"] * 1e9 if d["bound"] == "mfma" else d["algorithmic_mbytes_per_launch"] * 1e6
+            rate = work / avg / (1e12 if d["bound"] == "mfma" else 1e9)
+            d["in_network"] = {"avg_launch_ms": round(avg * 1e3, 4), "achieved": round(rate, 1), "frac": round(rate / d["peak"], 4),
+                               "source": f"rocprofv3 --kernel-trace --stats of `bench.py --serial-detectors`, profiles/{rocprof_src} ({calls} launches)"}
         return d
+
+    def describe_group(label, members):
+        """one roofline record over several bench labels (launch-weighted: total work / total time)"""
+        n = sum(agg[k][0] for k in members)
+        fl, t, by = (sum(agg[k][i] for k in members) for i in (1, 2, 3))
+        agg[label] = [n, fl, t, by]
+        d = with_traffic(describe(label), kernels=members)
+        del agg[label]
+        d["members"] = {k: {"launches": agg[k][0], "ms": round(agg[k][2] * 1e3, 3), "tflops": round(agg[k][1] / agg[k][2] / 1e12, 1),
+                            "algorithmic_gbs": round(agg[k][3] / agg[k][2] / 1e9, 0)} for k in members}
+        return d
+
     dom = max(agg, key=lambda k: agg[k][2])
     out = with_traffic(describe(dom))
-    # north_star's MFMA target is quoted on the 3x3 convolutions: always report their kernel as well
-    # (the pure 3x3 launches; the fused forms - "..., 1>" = 3x3 + RPN head, "..., 2>" = 3x3 + conv3 + shortcut of a bottleneck,
-    #  whose second half is HBM-bound - are listed in all_conv_variants)
-    pure = [k for k in agg if k.startswith("conv3x3_wd") and k.endswith(", 0>")] or [k for k in agg if k.startswith("conv3x3")]
+    # north_star's MFMA target is quoted on "the ResNet-101 3x3 convs": the kernels that CONTAIN the bottom-up 3x3 convolutions - res2 as
+    # fused 64-wide chains (bneck64: 1x1 + 3x3 + 1x1 per launch), res3's kw-reuse kernel, the fused res4 tail (3x3 + conv3 + shortcut)
+    # and res5's weights-direct kernel - with their flops (whole launches, i.e. including the fused 1x1 halves), their time and the
+    # launch-weighted fraction of the fp16 MFMA peak
+    bottom_up = [k for k in agg if k.startswith("bneck64_kernel") or k.endswith(", 0, 2>") or k.startswith("conv3x3_wd9_tail") or " @res" in k]
+    if bottom_up:
+        d = describe_group("resnet bottom-up 3x3 (res2 chains, res3, res4 tail, res5)", bottom_up)
+        d.update({"bound": "mfma", "achieved": d["tflops"], "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
+                  "frac": round(d["tflops"] / MFMA_F16_DENSE_PEAK_TFLOPS, 4)})
+        if "in_network" in d:
+            # per member: its flops at rocprof's average duration of its kernel NAME (res5 shares a name with the p5 output conv: 2 of 8
+            # launches of that name are not the backbone's)
+            tot = sum(agg[k][0] * (sum(v[1] for v in same_template(rocprof, k)) / max(sum(v[0] for v in same_template(rocprof, k)), 1)) for k in bottom_up) * 1e-9
+            tf = sum(agg[k][1] for k in bottom_up) / tot / 1e12
+            d["in_network"].update({"avg_launch_ms": round(tot / sum(agg[k][0] for k in bottom_up) * 1e3, 4), "achieved": round(tf, 1),
+                                    "frac": round(tf / MFMA_F16_DENSE_PEAK_TFLOPS, 4)})
+        out["resnet3x3"] = d
+    # the FPN output convolutions and the RPN head's 3x3 (pure 3x3 launches; "..., 1>" = 3x3 + RPN head)
+    pure = [k for k in agg if k.startswith("conv3x3_wd") and k.endswith(", 0>")] or [k for k in agg if k.startswith("conv3x3") and k not in bottom_up]
     k3 = max(pure, key=lambda k: agg[k][1], default=None)
     if k3 is not None and k3 != dom:
         out["conv3x3"] = with_traffic(describe(k3))
-    # ... and the HBM-bound 1x1 class (the dominant kernel of rounds 1-2 until the res4 tails and res2 were fused; it and the fused
-    # bottleneck tail now take about the same share of a step, so which of the two is "dominant" can flip between runs)
-    k1 = max((k for k in agg if k.startswith("conv_igemm2_kernel<128, 128")), key=lambda k: agg[k][2], default=None)
-    if k1 is not None and k1 != dom:
-        out["conv1x1"] = with_traffic(describe(k1))
-    # ... and the fused res4 bottleneck tail (the dominant kernel of rounds 2-3; round 4's line stores put it behind the 1x1 class)
+    # the HBM-bound 1x1 class: every 1x1 launch below the machine balance (conv_igemm2's 128-wide tiles and the persistent ring kernel;
+    # the box head's long-K GEMMs are MFMA-bound and listed on their own)
+    ring_hbm = [k for k in agg if k == "conv1x1_ring_kernel"]
+    one = [k for k in agg if k.startswith("conv_igemm2_kernel<128, 128") and " @" not in k] + ring_hbm
+    if one:
+        out["conv1x1"] = describe_group("1x1 class (conv_igemm2<128,128> + conv1x1_ring)", one)
+    if ring_hbm and ring_hbm[0] != dom:
+        out["conv1x1_ring"] = with_traffic(describe(ring_hbm[0]))
+    # ... and the fused res4 bottleneck tail
     kt = max((k for k in agg if k.endswith(", 0, 2>") or k.startswith("conv3x3_wd9_tail")), key=lambda k: agg[k][2], default=None)
     if kt is not None and kt != dom:
         out["res4_tail"] = with_traffic(describe(kt))
-    out["method"] = ("avg_launch_ms = HIP-event timing of every distinct launch replayed back-to-back on the launch stream; "
-                     "agrees with rocprofv3 --kernel-trace --stats of `bench.py --serial-detectors` (profiles/).  In the default "
-                     "two-stream run co-running kernels stretch each other's durations while the step gets shorter.")
+    out["method"] = ("avg_launch_ms / achieved / frac = HIP-event timing of every distinct launch replayed back-to-back on the launch stream: "
+                     "WARM-cache figures (a launch's inputs may still sit in the 256 MiB Infinity Cache from its previous replay; inside the "
+                     "network they were just written by the producer or are cold) - `in_network` holds rocprofv3's average duration of the "
+                     "same kernels inside `bench.py --serial-detectors` from the committed profile of the round (" + (rocprof_src or "none committed yet") +
+                     "), typically 3-8 % slower.  In the default two-stream run co-running kernels stretch each other's durations while the step gets shorter.")
     out["all_conv_variants"] = {k: {"launches": v[0], "gflop": round(v[1] / 1e9, 1), "ms": round(v[2] * 1e3, 3),
                                     "tflops": round(v[1] / v[2] / 1e12, 1), "algorithmic_gbs": round(v[3] / v[2] / 1e9, 0)}
                                 for k, v in sorted(agg.items(), key=lambda kv: -kv[1][2])}
@@ -443,9 +500,9 @@ def main(argv=None):
     cfg = CONFIGS[args.config]
     depth = args.depth or cfg["depth"]
     B = args.batch or cfg["batch"]
-    if args.wd9_tail_wgs > 0 or args.wd9_wgs > 0:
+    if args.wd9_wgs > 0:
         from proben_amd import _lib
-        _lib.test_hooks().pe_test_set_wd9_wgs(args.wd9_wgs, args.wd9_tail_wgs)
+        _lib.test_hooks().pe_test_set_wd9_wgs(args.wd9_wgs, 0)
     if not args.roi_sort:
         from proben_amd import layers as _layers
         _layers.ROI_SORT = False
@@ -514,9 +571,8 @@ def main(argv=None):
                                            "frames in pinned host memory; double-buffered H2D upload of every batch INSIDE the timed region"),
                        "timed_seconds": round(dt, 2), "schedule": sched,
                        "persistent_kernels": ("csrc/conv_wd9.h (pure 3x3 and the fused RPN head, one 512-register workgroup per CU) takes the 256 -> 256 launches of >= 128 tiles; "
-                                              "csrc/conv_wd9_tail.h (fused res4 tail on the same structure) is "
-                                              + ("ON (--wd9-mode)" if args.wd9_mode >= 0 and args.wd9_mode & 4 else
-                                                 "opt-in and OFF here: faster as a launch of its own, slower in every pipeline (DESIGN.md 10.4)"))},
+                                              "csrc/conv1x1_ring.hip (loader / consumer 1x1 kernel, one 160-KiB workgroup per CU) takes the stride-1 residual-free 1x1 "
+                                              "layers with K >= 512 and Cout % 256 == 0 (res4 / res5 conv1, top lateral, fc1, fc2)")},
         }
         if power is not None:
             line["power"] = power.result(w0, w1, B * args.steps)    # rank 0's board, rank 0's units

@@ -3,7 +3,6 @@
 
 namespace pe {
 int wd9_conv3x3(ConvWdArgs a, hipStream_t st);   // csrc/conv_wd9.hip: the large launches of the same layers, same bits
-int wd9_bottleneck_tail(ConvWdArgs a, hipStream_t st);   // csrc/conv_wd9.hip: res4 geometry (image width 64), chosen by geometry only
 int wd9_rpn_head(ConvWdArgs a, hipStream_t st);   // csrc/conv_wd9.hip: the fused RPN head on the one-wave structure, same bits
 }
 
@@ -123,8 +122,7 @@ extern "C" int pe_bottleneck_tail_wd_f16(const void* input, const void* packed_w
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = 256; a.M = (int)M; a.relu = 1; a.out_stride = 256;
     a.tail_w = (const _Float16*)packed_tail; a.tail_b = tail_bias; a.tail_res = (const _Float16*)residual;
     a.tail_out = (_Float16*)output; a.tail_cout = tail_cout;
-    int st = pe::wd9_bottleneck_tail(a, (hipStream_t)stream);
-    if (st == PE_ERR_UNSUPPORTED) st = wd::launch_conv3x3_wd<1, 4, 4, 4, 0, 2>(a, (hipStream_t)stream);
+    int st = wd::launch_conv3x3_wd<1, 4, 4, 4, 0, 2>(a, (hipStream_t)stream);
     if (st != PE_OK) {
         pe::set_error("pe_bottleneck_tail_wd_f16: unsupported geometry");
         return st;

@@ -12,20 +12,17 @@ extern "C" {
  *                                64: ... for every eligible 1x1 launch (stride 1, no residual, fp16 out, K >= 512, Cout % 256 == 0)
  *   reuse3x3 (default 1): 1 = kw-reuse 3x3 kernel, 0 = generic per-tap 3x3 kernel */
 int pe_test_set_conv_policy(int tile_bits, int reuse3x3);
-/* Which generation of the weights-direct kernels takes a launch.  Bit mask (default 1 | 8; the tail kernel is opt-in, csrc/conv_wd9.hip;
- * a negative mode restores the default):
+/* Which generation of the weights-direct kernels takes a launch.  Bit mask (default 1 | 8; a negative mode restores the default;
+ * bit 2 was round 4's fused tail on this structure, now scripts/lab/conv_wd9_tail.h):
  *   1 = pure 3x3: conv_wd9.h for launches of >= 128 tiles of 256 pixels (same bits as conv_wd.h)   2 = ... whenever the geometry allows
- *   4 = fused bottleneck tail: conv_wd9_tail.h for image width 64 (chosen by geometry only)
  *   8 = fused RPN head: conv_wd9.h's head epilogue under the size rule of bit 0 / bit 1 (same bits)  0 = conv_wd.h only */
 int pe_test_set_wd9_mode(int mode);
 /* 1 when a 3x3 launch of this shape is taken by the conv_wd9.h kernel under the current mode (bench.py labels its kernel table with it) */
 int pe_test_wd9_takes(int N, int H, int W, int Cin, int Cout);
 /* the same for the fused RPN head (pe_conv3x3_wd_rpn_head_f16) */
 int pe_test_wd9_head_takes(int N, int H, int W);
-/* 1 when a fused bottleneck tail of this geometry runs on csrc/conv_wd9_tail.h (image width 64; independent of the batch size) */
-int pe_test_wd9_tail_takes(int H, int W, int Cin, int tail_cout);
-/* workgroups of the persistent kernels (multiples of 8 in 8 .. 256; 0 = leave unchanged; default 256 = one per CU): what leaving CUs
- * to the other detector's stream is worth (scripts/r04_ab2.sh) */
+/* workgroups of the persistent 3x3 kernels (multiples of 8 in 8 .. 256; 0 = leave unchanged; default 256 = one per CU): what leaving CUs
+ * to the other detector's stream is worth (scripts/r04_ab2.sh); the second argument is ignored (it sized the round-4 tail kernel) */
 int pe_test_set_wd9_wgs(int pure, int tail);
 /* workgroups of the persistent 1x1 ring kernel (default 256 = one per CU) */
 int pe_test_set_ring_wgs(int wgs);

@@ -75,7 +75,7 @@ class BoxHeadFineTuner:
         self.model, self.cfg = model, model.cfg
         K = self.cfg.num_classes
         self.S, self.pf, self.loss_scale, self.clip = batch_size_per_image, positive_fraction, loss_scale, clip_grad_norm
-        self.head = BoxHead(49 * 256, K, model.device, seed=seed)
+        self.head = BoxHead(49 * model.w.rpn_channels, K, model.device, seed=seed)      # 49 x 256, 49 x 512 for a middle-fusion model
         if init_from_model:
             self.load_from_model()
         self.opt = FusedSGD(self.head.flat, lr=lr, momentum=momentum, weight_decay=weight_decay)
@@ -100,6 +100,22 @@ class BoxHeadFineTuner:
             w.fc2 = (f.half("fc2.weight").clone(), f["fc2.bias"].detach().clone())
             w.predictor = (f.half("predictor.weight")[:n].clone().contiguous(), f["predictor.bias"].detach()[:n].clone())
             w.has_var = True
+
+    def reference_state_dict(self):
+        """The trained head under the REFERENCE's checkpoint keys (what DetectionCheckpointer saves and `weights.load_state_dict_file`
+        / `GeneralizedRCNN` load): `roi_heads.box_head.fc{1,2}.{weight,bias}` with fc1's columns back in the reference's (c, ph, pw)
+        order (the inverse of weights.py's permutation to the ROIAlign kernel's (ph, pw, c)), and the fused predictor split back into
+        `roi_heads.box_predictor.{cls_score,bbox_pred,var_pred}.{weight,bias}` without its zero padding."""
+        f, K, C = self.head.flat, self.head.K, self.model.w.rpn_channels
+        w1 = f["fc1.weight"].detach().float().cpu()
+        w1 = w1.view(w1.shape[0], 7, 7, C).permute(0, 3, 1, 2).reshape(w1.shape[0], 49 * C).contiguous()
+        pw, pb = f["predictor.weight"].detach().float().cpu(), f["predictor.bias"].detach().float().cpu()
+        q, h = "roi_heads.box_predictor.", "roi_heads.box_head."
+        return {h + "fc1.weight": w1, h + "fc1.bias": f["fc1.bias"].detach().float().cpu().clone(),
+                h + "fc2.weight": f["fc2.weight"].detach().float().cpu().clone(), h + "fc2.bias": f["fc2.bias"].detach().float().cpu().clone(),
+                q + "cls_score.weight": pw[:K + 1].clone(), q + "cls_score.bias": pb[:K + 1].clone(),
+                q + "bbox_pred.weight": pw[K + 1:5 * K + 1].clone(), q + "bbox_pred.bias": pb[K + 1:5 * K + 1].clone(),
+                q + "var_pred.weight": pw[5 * K + 1:5 * K + 2].clone(), q + "var_pred.bias": pb[5 * K + 1:5 * K + 2].clone()}
 
     def state_dict(self):
         """What a resumed run needs (the reference's DetectionCheckpointer saves model + optimizer + scheduler, engine/defaults.py:264-275):
@@ -129,10 +145,11 @@ class BoxHeadFineTuner:
         detector's input size like the reference's dataset mapper does with its transforms)."""
         feats, props, pcnt, sizes = self._features(frames, resize_to)
         N = props.shape[0]
-        h0, w0 = (frames.shape[1], frames.shape[2]) if isinstance(frames, torch.Tensor) else (frames[0].shape[0], frames[0].shape[1])
-        sy, sx = sizes[0][0] / h0, sizes[0][1] / w0
-        scale = torch.tensor([sx, sy, sx, sy])
-        gtb = [b.float().cpu() * scale for b in gt_boxes]
+        gtb = []
+        for n in range(N):      # every image by its own frame size and its own resized size
+            h0, w0 = (frames.shape[1], frames.shape[2]) if isinstance(frames, torch.Tensor) else (frames[n].shape[0], frames[n].shape[1])
+            sy, sx = sizes[n][0] / h0, sizes[n][1] / w0
+            gtb.append(gt_boxes[n].float().cpu().reshape(-1, 4) * torch.tensor([sx, sy, sx, sy]))
         boxes, live, classes, matched = label_and_sample_proposals(props, pcnt, gtb, gt_classes, self.cfg.num_classes, self.S, self.pf, generator=self.gen)
         pooled = L.roi_align_nhwc(feats[:4], boxes, scales=[1 / 4, 1 / 8, 1 / 16, 1 / 32], pooled=(7, 7), sampling_ratio=0, aligned=True,
                                   counts=live, per_image=self.S, num_rois=N * self.S)

@@ -228,8 +228,9 @@ def conv2d_nhwc(x, weight, bias, *, kernel, stride=1, relu=False, residual=None,
 
 
 def set_concurrent_streams(n):
-    """Tell the library how many detectors run concurrently on their own HIP streams (pipeline.py): its persistent kernels then
-    leave CUs to the other streams' launches.  Process-global; never changes results."""
+    """Tell the library how many detectors run concurrently on their own HIP streams (pipeline.py).  Validated and, since round 5,
+    otherwise ignored: the persistent kernels that ship measured best at one workgroup per CU under 1, 2 and 3 streams (the hint sized
+    round 4's opt-in fused-tail kernel, which left the library).  Process-global; never changes results."""
     _lib.check(_lib.lib().pe_conv_wd_set_concurrent_streams(int(n)), "pe_conv_wd_set_concurrent_streams")
 
 
@@ -293,8 +294,7 @@ def bottleneck_tail_wd(x, packed3x3, bias3x3, packed_tail, tail_bias, residual, 
     _lib.check(st, "pe_bottleneck_tail_wd_f16")
     if PROFILE is not None:
         M = N * H * W
-        wd9 = _lib.test_hooks().pe_test_wd9_tail_takes(H, W, Cin, tail_cout)
-        PROFILE.append({"variant": "conv3x3_wd9_tail_kernel<4, 4>" if wd9 else "conv3x3_wd_kernel<1, 4, 4, 4, 0, 2>",
+        PROFILE.append({"variant": "conv3x3_wd_kernel<1, 4, 4, 4, 0, 2>",
                         "shape": f"N{N} {H}x{W} Cin{Cin} Cout256->{tail_cout} k3+k1 s1 res{int(residual is not None)} f320",
                         "flops": 2.0 * M * 256 * 9 * Cin + 2.0 * M * tail_cout * 256,
                         "bytes": float(M * Cin * 2 + 256 * 9 * Cin * 2 + tail_cout * 256 * 2 + M * tail_cout * 2 * (2 if residual is not None else 1)),

@@ -175,6 +175,8 @@ class BucketedGradAllReduce:
         import torch.distributed as dist
         self.dist, self.flat, self.group = dist, flat, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # flags that must agree over ranks travel on the device with RCCL, on the host with gloo
+        self.backend_is_device = bool(dist.is_initialized() and dist.get_backend(group) != "gloo")
         self.collective = dist.is_initialized()      # a ONE-rank group (PROBEN_FORCE_DIST=1) still runs its collectives: the RCCL path on a one-GPU box
         self.buckets, self.bucket_of = [], {}
         hi, cur = flat.numel, []
@@ -311,21 +313,38 @@ def box_head_train_step(head, optimizer, reducer, pooled, proposals, gt_boxes, g
                         smooth_l1_beta=0.0, clip_grad_norm=0.0):
     """One SGD step of the box head on frozen features: forward (HIP GEMMs) -> FastRCNNLosses -> backward (HIP GEMMs; the loss is
     scaled so that fp16 activation gradients do not underflow) -> bucketed all-reduce (overlapped) -> fused SGD with
-    grad_scale = 1 / (world_size x loss_scale) (x the clipping factor of SOLVER.CLIP_GRADIENTS, norm type 2 over all parameters, when
-    `clip_grad_norm` > 0: solver/build.py:19-36).  Returns the unscaled losses; a non-finite loss raises instead of stepping."""
+    grad_scale = 1 / (world_size x loss_scale).  `clip_grad_norm` > 0 = SOLVER.CLIP_GRADIENTS with CLIP_TYPE "norm", NORM_TYPE 2:
+    like the reference's `optimizer_wgc_step` (solver/build.py:19-36, 66-90) every parameter TENSOR is clipped by its own norm.
+    Returns the unscaled losses (+ "skipped": 1.0 when the step was not applied).
+
+    Non-finite values are handled COLLECTIVELY, so that no rank leaves its peers waiting in an all-reduce: a non-finite loss on any
+    rank is agreed on over the process group BEFORE backward and raises FloatingPointError on every rank; a non-finite gradient
+    after the all-reduce (an fp16 overflow of the scaled activation gradients - every rank sees the same reduced buffer) skips the
+    step on every rank and leaves weights, momentum and the fp16 shadow untouched."""
     head.flat.zero_grad()
     scores, deltas, variance = head.forward(pooled)
     losses = FastRCNNLosses(box2box_transform, scores, deltas, variance, proposals, gt_boxes, gt_classes, smooth_l1_beta).losses()
     total = sum(losses.values())
     out = {k: float(v.detach()) for k, v in losses.items()}
-    if not all(math.isfinite(v) for v in out.values()):
-        raise FloatingPointError(f"box-head training diverged (losses {out}): lower the learning rate or clip gradients")
+    bad = 0.0 if all(math.isfinite(v) for v in out.values()) else 1.0
+    if reducer is not None and reducer.world > 1:
+        flag = torch.tensor([bad], device=head.flat.grad.device if reducer.backend_is_device else "cpu")
+        torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX, group=reducer.group)
+        bad = float(flag.item())
+    if bad:
+        raise FloatingPointError(f"box-head training diverged on at least one rank (this rank's losses {out}): lower the learning rate or clip gradients")
     (total * loss_scale).backward()
     scale = (reducer.finish() if reducer is not None else 1.0) / loss_scale
+    flat = head.flat
+    if not bool(torch.isfinite(flat.grad).all()):
+        out["skipped"] = 1.0
+        return out
     if clip_grad_norm > 0:
-        norm = float(head.flat.grad.norm()) * scale
-        if not math.isfinite(norm):
-            raise FloatingPointError("box-head training: non-finite gradient norm")
-        scale *= min(1.0, clip_grad_norm / (norm + 1e-6))
+        for name in flat.names:
+            o, n = flat.offsets[name]
+            g = flat.grad[o:o + n]
+            coef = clip_grad_norm / (float(g.norm()) * scale + 1e-6)
+            if coef < 1.0:
+                g.mul_(coef)
     optimizer.step(grad_scale=scale)
     return out

@@ -305,51 +305,6 @@ def test_fused_bottleneck_tail_matches_two_launch_path_and_torch(L, shape):
     torch.testing.assert_close(outs[0].float(), ref, rtol=5e-3, atol=5e-3)
 
 
-@pytest.mark.parametrize("shape", [(3, 7, 64, 64, 256, True), (1, 50, 64, 256, 1024, False), (5, 13, 64, 128, 512, True), (40, 4, 64, 256, 1024, True)])
-def test_fused_bottleneck_tail_wd9_geometry(L, shape):
-    """csrc/conv_wd9_tail.h (image width 64: persistent workgroups over runs of image rows, 3-row and 1-row tiles, the shortcut added
-    through the matrix pipe, whole-line stores) against torch fp32 and the two-launch path: three K groups only (Cin 64), no
-    shortcut, H not a multiple of the tile, more workgroups than rows / 3, image seams inside tiles.  Twice (race screen: DMA ring
-    slots that double as the t copy and the store patches), and frame by frame == in the batch (the kernel is chosen by geometry,
-    never by batch size)."""
-    from proben_amd import _lib
-    N, H, W, Cin, CoutT, with_res = shape
-    _lib.test_hooks().pe_test_set_wd9_mode(1 | 4)      # the tail kernel is opt-in (csrc/conv_wd9.hip)
-    assert _lib.test_hooks().pe_test_wd9_tail_takes(H, W, Cin, CoutT) == 1
-    g = torch.Generator(device="cpu").manual_seed(41)
-    x = torch.randn(N, Cin, H, W, generator=g).cuda().half().relu()
-    w2 = (torch.randn(256, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5).cuda().half()
-    b2 = torch.randn(256, generator=g).cuda()
-    w3 = (torch.randn(CoutT, 256, 1, 1, generator=g) / 16.0).cuda().half()
-    b3 = torch.randn(CoutT, generator=g).cuda()
-    res = torch.randn(N, CoutT, H, W, generator=g).cuda().half() if with_res else None
-    t_ref = torch.nn.functional.conv2d(x.float(), w2.float(), b2, padding=1).relu()
-    ref = torch.nn.functional.conv2d(t_ref, w3.float(), b3)
-    if with_res:
-        ref = ref + res.float()
-    ref = ref.relu().permute(0, 2, 3, 1)
-    p2 = L.conv_wd_pack(w2.permute(0, 2, 3, 1).contiguous())
-    p3 = L.conv_wd_pack_tail(w3.reshape(CoutT, 256).contiguous())
-    r = nhwc(res) if with_res else None
-    xs = nhwc(x)
-    outs = [L.bottleneck_tail_wd(xs, p2, b2, p3, b3, r, CoutT) for _ in range(2)]
-    torch.cuda.synchronize()
-    assert torch.equal(outs[0], outs[1])
-    t = L.conv3x3_wd(xs, p2, b2, 256, relu=True)
-    two = L.conv2d_nhwc(t, w3.permute(0, 2, 3, 1).contiguous(), b3, kernel=1, relu=True, residual=r, residual_mode=1 if with_res else 0)
-    torch.testing.assert_close(outs[0].float(), two.float(), rtol=2e-3, atol=2e-3)
-    torch.testing.assert_close(outs[0].float(), ref, rtol=5e-3, atol=5e-3)
-    for n in (0, N - 1):
-        one = L.bottleneck_tail_wd(xs[n:n + 1].contiguous(), p2, b2, p3, b3, None if r is None else r[n:n + 1].contiguous(), CoutT)
-        assert torch.equal(one[0], outs[0][n])
-    # the number of workgroups (what pe_conv_wd_set_concurrent_streams changes) moves tile boundaries, never results
-    L.set_concurrent_streams(2)
-    half = L.bottleneck_tail_wd(xs, p2, b2, p3, b3, r, CoutT)
-    L.set_concurrent_streams(1)
-    assert torch.equal(half, outs[0])
-    _lib.test_hooks().pe_test_set_wd9_mode(-1)
-
-
 @pytest.mark.parametrize("shape", [(2, 8, 64, True, True), (1, 7, 70, False, True), (3, 5, 32, False, False), (2, 13, 130, True, False), (1, 50, 64, False, True)])
 def test_fused_bneck64_chain_matches_torch_and_unfused_kernels(L, shape):
     """A res2 bottleneck from its 3x3 on + the next block's conv1 (backbone/resnet.py:107-221) in one launch == torch fp32 with

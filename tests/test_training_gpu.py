@@ -194,3 +194,58 @@ def test_fine_tuner_checkpoint_resume_is_exact(golden_dir):
     with pytest.raises(ValueError):
         ckpt["names"] = ckpt["names"][::-1]
         b.load_state_dict(ckpt)
+
+
+def test_trained_head_exports_under_the_references_keys_and_loads_back(golden_dir, tmp_path):
+    """a fine-tuned head must come back through `--weights` / `--model_path`.  `reference_state_dict()` gives
+    the head under the reference's checkpoint keys (fc1 un-permuted to (c, ph, pw), the fused predictor split into cls_score /
+    bbox_pred / var_pred); the file `cli/train_box_head.py --out` writes ({"model": whole detector, "optimizer", "iteration"}) loads
+    through weights.load_state_dict_file into a NEW GeneralizedRCNN that detects exactly what the tuner's in-place `export()` does,
+    and per-tensor gradient clipping / the collective non-finite handling leave the run finite."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from parity_map import load_fixture
+    from proben_amd.data import resize_shortest_edge_shape
+    from proben_amd.finetune import BoxHeadFineTuner
+    from proben_amd.rcnn import DetectorConfig, GeneralizedRCNN
+    from proben_amd.synthetic import labelled_frames
+    from proben_amd.weights import load_state_dict_file
+    _, sd, _, _ = load_fixture(golden_dir)
+    model = GeneralizedRCNN(DetectorConfig(), sd)
+    tuner = BoxHeadFineTuner(model, lr=0.002, seed=5, init_from_model=True, clip_grad_norm=0.5)
+    new_hw = resize_shortest_edge_shape(512, 640, 800, 1333)
+    for step in range(3):
+        frames, gts = labelled_frames(2, seed=8100 + step)
+        losses = tuner.step(torch.from_numpy(frames).cuda(), [torch.from_numpy(b) for b, _ in gts], [torch.from_numpy(c) for _, c in gts], resize_to=new_hw)
+        assert all(math.isfinite(v) for v in losses.values()) and "skipped" not in losses
+    ref = tuner.reference_state_dict()
+    K = model.cfg.num_classes
+    assert {k: tuple(v.shape) for k, v in ref.items()} == {
+        "roi_heads.box_head.fc1.weight": (1024, 256 * 49), "roi_heads.box_head.fc1.bias": (1024,),
+        "roi_heads.box_head.fc2.weight": (1024, 1024), "roi_heads.box_head.fc2.bias": (1024,),
+        "roi_heads.box_predictor.cls_score.weight": (K + 1, 1024), "roi_heads.box_predictor.cls_score.bias": (K + 1,),
+        "roi_heads.box_predictor.bbox_pred.weight": (4 * K, 1024), "roi_heads.box_predictor.bbox_pred.bias": (4 * K,),
+        "roi_heads.box_predictor.var_pred.weight": (1, 1024), "roi_heads.box_predictor.var_pred.bias": (1,)}
+    # the file of `train_box_head --out`
+    full = {k: (v.detach().cpu() if isinstance(v, torch.Tensor) else torch.as_tensor(v)) for k, v in sd.items()}
+    full.update(ref)
+    path = tmp_path / "model_final.pth"
+    torch.save({"model": full, "optimizer": tuner.state_dict(), "iteration": 3}, path)
+    tuner.export()
+    held, _ = labelled_frames(4, seed=9100)
+    frames = torch.from_numpy(held).cuda()
+    a = model.forward_batch(frames, resize_to=new_hw)
+    again = GeneralizedRCNN(DetectorConfig(), load_state_dict_file(str(path)))
+    b = again.forward_batch(frames, resize_to=new_hw)
+    assert torch.equal(a["counts"], b["counts"]) and int(a["counts"].sum()) > 0
+    for n, c in enumerate(a["counts"].tolist()):
+        for k in ("boxes", "scores", "classes", "vars"):
+            assert torch.equal(a[k][n, :c], b[k][n, :c]), (k, n)
+    # resume: optimizer state from the file continues with the same bits as the uninterrupted tuner
+    t2 = BoxHeadFineTuner(again, lr=0.9, seed=77, init_from_model=True, clip_grad_norm=0.5)
+    t2.load_state_dict(torch.load(path, map_location="cpu")["optimizer"])
+    frames2, gts2 = labelled_frames(2, seed=8200)
+    args = (torch.from_numpy(frames2).cuda(), [torch.from_numpy(b) for b, _ in gts2], [torch.from_numpy(c) for _, c in gts2])
+    assert tuner.step(*args, resize_to=new_hw) == t2.step(*args, resize_to=new_hw)
+    assert torch.equal(tuner.head.flat.master, t2.head.flat.master)
