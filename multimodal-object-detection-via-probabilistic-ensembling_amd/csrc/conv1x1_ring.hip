@@ -52,6 +52,8 @@ struct RingArgs {
     int M, K, Cout, out_stride, relu;
     int nblk;      // 32-pixel blocks in the launch
     int tiles_n;   // Cout / 256
+    int stride, H, W, Ho, Wo;
+    unsigned in_bytes;           // stride 2 (shortcut convolutions): output pixel (n, oh, ow) reads input pixel (n, 2 oh, 2 ow) of [N, H, W, K]
     int abl;       // measurement builds (results wrong): 1 = no pixel DMA, 2 = no weight DMA, 4 = no ds_read / MFMA, 8 = no stores,
                    // 16 = pixel slabs fetched as if the input were K-chunk-major [K / 64][M][64] (contiguous 16 KiB per slab)
 };
@@ -201,7 +203,8 @@ __global__ __launch_bounds__(RG_THREADS) void conv1x1_ring_kernel(RingArgs a) {
             const int r = q * 8 + lrow;
             rel[q] = (unsigned)((r * a.K + ((lp ^ ((r >> 1) & 7)) * 8)) * 2);
         }
-        const int4v rs = rg_make_rsrc(a.in, (unsigned)a.M * (unsigned)a.K * 2u);
+        const int4v rs = rg_make_rsrc(a.in, (unsigned)a.in_bytes);
+        unsigned srow[16];          // strided launches only
         int u_ks = 0, u_n = 0, u_mt = 0;
         auto issue = [&](int stage) {
             const int mrow0 = (b0 + 4 * u_mt) * 32;
@@ -214,8 +217,24 @@ __global__ __launch_bounds__(RG_THREADS) void conv1x1_ring_kernel(RingArgs a) {
                 soff = (unsigned)(mrow0 * a.K + u_ks * 64) * 2u;
             }
             unsigned vo[16];
+            if (a.stride == 1) {
 #pragma unroll
-            for (int q = 0; q < 16; ++q) vo[q] = (q * 8 + lrow < vrows) ? rel[q] : RG_OOB;
+                for (int q = 0; q < 16; ++q) vo[q] = (q * 8 + lrow < vrows) ? rel[q] : RG_OOB;
+            } else {
+                // strided launch: the rows of a tile are not one run of the input; their offsets change with the m-tile only
+                if (u_ks == 0 && u_n == 0) {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const int r = q * 8 + lrow, m = mrow0 + r;
+                        const int ow = m % a.Wo, t = m / a.Wo;
+                        const int oh = t % a.Ho, n = t / a.Ho;
+                        srow[q] = r < vrows ? (unsigned)((((n * a.H + oh * a.stride) * a.W + ow * a.stride) * a.K + ((lp ^ ((r >> 1) & 7)) * 8)) * 2) : RG_OOB;
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 16; ++q) vo[q] = srow[q];
+                soff = u_mt < nmt ? (unsigned)(u_ks * 128) : 0u;
+            }
             const unsigned lds = smem_base + stage * RG_ASTAGE_B;
             if (a.abl & 16) {
                 soff = u_mt < nmt ? (unsigned)((u_ks * a.M + mrow0) * 128) : 0u;
@@ -375,16 +394,18 @@ std::atomic<int> g_ring_wgs{256};
 std::atomic<int> g_ring_abl{0};
 
 // true when the ring kernel can take the launch (the caller has checked: 1x1, stride 1, no residual, fp16 output)
-bool conv1x1_ring_eligible(int M, int K, int Cout, int cout_store, int out_stride) {
-    return Cout % RG_BN == 0 && cout_store == Cout && K % 64 == 0 && (long long)M * K * 2 < (1ll << 31) &&
+bool conv1x1_ring_eligible(int M, int K, int Cout, int cout_store, int out_stride, long long in_pixels) {
+    return Cout % RG_BN == 0 && cout_store == Cout && K % 64 == 0 && in_pixels * K * 2 < (1ll << 31) &&
            (long long)Cout * K * 2 < (1ll << 31) && (long long)M * out_stride * 2 < (1ll << 31);
 }
 
-int conv1x1_ring_launch(const void* in, const void* wgt, const float* bias, void* out, int M, int K, int Cout, int out_stride, int relu,
-                        hipStream_t st) {
+int conv1x1_ring_launch(const void* in, const void* wgt, const float* bias, void* out, int N, int H, int W, int Ho, int Wo, int stride, int M,
+                        int K, int Cout, int out_stride, int relu, hipStream_t st) {
     RingArgs a{};
     a.in = (const _Float16*)in; a.wgt = (const _Float16*)wgt; a.bias = bias; a.out = (_Float16*)out;
     a.M = M; a.K = K; a.Cout = Cout; a.out_stride = out_stride; a.relu = relu;
+    a.stride = stride; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo;
+    a.in_bytes = (unsigned)((long long)N * H * W * K * 2);
     a.nblk = pe::ceil_div(M, 32);
     a.tiles_n = Cout / RG_BN;
     a.abl = g_ring_abl.load(std::memory_order_relaxed);

@@ -212,7 +212,7 @@ def conv2d_nhwc(x, weight, bias, *, kernel, stride=1, relu=False, residual=None,
     _lib.check(st, "pe_conv2d_nhwc_f16")
     if PROFILE is not None:  # bench.py roofline leg: remember the launch so it can be replayed back-to-back
         variant = conv_variant_name(N * Ho * Wo, Cout, kernel, Cin if kernel == 1 else 0, stride=stride, residual_mode=residual_mode,
-                                    out_f32=out_f32, has_bias=bias is not None, cout_store=cout_store, out_stride=out_stride)
+                                    out_f32=out_f32, has_bias=bias is not None, cout_store=cout_store, out_stride=out_stride, in_pixels=N * H * W)
         cin_real = 3 if kernel == 7 else Cin
         shape = f"N{N} {H}x{W} Cin{Cin} Cout{Cout} k{kernel} s{stride} res{residual_mode} f32{int(out_f32)}"
         M = N * Ho * Wo
@@ -375,15 +375,15 @@ def conv3x3_wd_rpn_head(x, packed, bias, packed_head, head_bias16, out=None):
 DEFAULT_CONV_POLICY = 73   # tile_bits of csrc/test_hooks.h pe_test_set_conv_policy the library starts with (tests restore it)
 
 
-def conv_variant_name(M, Cout, kernel, K=0, *, stride=1, residual_mode=0, out_f32=False, has_bias=True, cout_store=0, out_stride=0):
+def conv_variant_name(M, Cout, kernel, K=0, *, stride=1, residual_mode=0, out_f32=False, has_bias=True, cout_store=0, out_stride=0, in_pixels=None):
     """Name of the kernel pe_conv2d_nhwc_f16 dispatches to under the DEFAULT policy (mirrors conv2_dispatch in
     csrc/conv_igemm2.hip; matches the rocprofv3 kernel names)."""
     bn = 64 if Cout <= 64 else 128
     if kernel == 7:
         return "conv_igemm_kernel<128, 64, 2>"          # 7x7 stem, register-staged kernel
     if kernel == 1:
-        ring = (stride == 1 and residual_mode == 0 and not out_f32 and has_bias and K >= 512 and Cout % 256 == 0
-                and (cout_store or Cout) == Cout and M * K * 2 < 2 ** 31 and Cout * K * 2 < 2 ** 31 and M * (out_stride or Cout) * 2 < 2 ** 31)
+        ring = (stride in (1, 2) and residual_mode == 0 and not out_f32 and has_bias and K >= (512 if stride == 1 else 256) and Cout % 256 == 0
+                and (cout_store or Cout) == Cout and (in_pixels or M) * K * 2 < 2 ** 31 and Cout * K * 2 < 2 ** 31 and M * (out_stride or Cout) * 2 < 2 ** 31)
         if ring:
             return "conv1x1_ring_kernel"                # persistent loader / consumer kernel (csrc/conv1x1_ring.hip)
         if K >= 4096 and Cout % 256 == 0 and ((M + 255) // 256) * (Cout // 256) >= 224:

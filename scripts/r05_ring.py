@@ -44,22 +44,26 @@ def main():
         md = (ref.float() - out.float()).abs().max().item()
         print(f"N{N} {H}x{W} {Cin}->{Cout} relu{relu} bias{bias}: identical={same} max|d|={md:.3g} nan={int(torch.isnan(out).sum())}", flush=True)
     print("# timing (ms per launch; GB/s = algorithmic bytes)")
-    for (N, H, W, Cin, Cout) in [(32, 50, 64, 1024, 256), (16, 50, 64, 1024, 256), (32, 25, 32, 2048, 512), (32, 25, 32, 2048, 256),
-                                 (32000, 1, 1, 1024, 1024), (32, 100, 128, 512, 256), (32000, 1, 1, 12544, 1024)]:
+    for shape in [(32, 50, 64, 1024, 256), (16, 50, 64, 1024, 256), (32, 25, 32, 2048, 512), (32, 25, 32, 2048, 256),
+                  (32000, 1, 1, 1024, 1024), (32, 100, 128, 512, 256), (32000, 1, 1, 12544, 1024),
+                  (32, 200, 256, 256, 512, 2), (32, 100, 128, 512, 1024, 2), (32, 50, 64, 1024, 2048, 2)]:
+        N, H, W, Cin, Cout = shape[:5]
+        stride = shape[5] if len(shape) > 5 else 1
         x = torch.randn(N, H, W, Cin, device="cuda").half().relu()
         w = (torch.randn(Cout, 1, 1, Cin, device="cuda") / Cin ** 0.5).half()
         b = torch.randn(Cout, device="cuda")
-        out = torch.empty(N, H, W, Cout, device="cuda", dtype=torch.float16)
-        M = N * H * W
+        Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+        out = torch.empty(N, Ho, Wo, Cout, device="cuda", dtype=torch.float16)
+        M = N * Ho * Wo
         nbytes = (M * Cin + Cout * Cin + M * Cout) * 2
         row = []
-        for name, pol, wgs in [("r04", 9, 256), ("ring256", 73, 256), ("ring224", 73, 224), ("ring128", 73, 128), ("r04", 9, 256), ("ring256", 73, 256)]:
+        for name, pol, wgs in [("r04", 9, 256), ("ring256", 73, 256), ("ring224", 73, 224), ("r04", 9, 256), ("ring256", 73, 256)]:
             hooks.pe_test_set_conv_policy(pol, 1)
             hooks.pe_test_set_ring_wgs(wgs)
-            ms = timeit(lambda: L.conv2d_nhwc(x, w, b, kernel=1, relu=True, out=out))
+            ms = timeit(lambda: L.conv2d_nhwc(x, w, b, kernel=1, stride=stride, relu=True, out=out))
             row.append(f"{name}: {ms:.4f} ms {nbytes / ms / 1e6:5.0f} GB/s")
         hooks.pe_test_set_ring_wgs(256)
-        print(f"N{N} {H}x{W} {Cin}->{Cout} | " + " | ".join(row), flush=True)
+        print(f"N{N} {H}x{W} {Cin}->{Cout} s{stride} | " + " | ".join(row), flush=True)
     hooks.pe_test_set_conv_policy(9, 1)
 
 

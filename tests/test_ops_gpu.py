@@ -104,6 +104,56 @@ def test_conv_big_tile_kernel(L, case, policy):
     torch.testing.assert_close(out.permute(0, 3, 1, 2).float(), ref, rtol=4e-3, atol=4e-3)
 
 
+@pytest.mark.parametrize("case", [
+    # N, H, W, Cin, Cout, relu[, stride]
+    (3, 50, 64, 1024, 256, True),       # res4 conv1: 300 blocks of 32 pixels over 256 workgroups (runs of 1 and 2 blocks)
+    (32, 50, 64, 1024, 256, True),      # ... at the bench's batch: runs of 12 / 13 blocks = 3 full tiles + a 1-block tile
+    (1, 13, 16, 2048, 256, False),      # M = 208 is not a multiple of 32: the last block is ragged, 7 workgroups
+    (2, 25, 32, 2048, 512, True),       # two column tiles walked by ONE workgroup per run (grid too small to pair them)
+    (4000, 1, 1, 1024, 1024, True),     # four column tiles on four workgroups of one XCD (fc2 shape)
+    (1, 7, 9, 512, 256, True),          # two blocks
+    (8, 100, 128, 256, 512, False, 2),  # stride 2: res3's shortcut convolution (K = 256), two column tiles
+    (3, 51, 65, 512, 1024, True, 2),    # stride 2 on odd sizes: 26 x 33 outputs, rows of a tile straddle image rows and images
+    (2, 50, 64, 1024, 2048, False, 2),  # res5's shortcut: eight column tiles
+])
+def test_conv1x1_ring_kernel_matches_torch_and_conv_igemm2_bit_for_bit(L, case):
+    """csrc/conv1x1_ring.hip (persistent loader / consumer 1x1 kernel, the default for residual-free 1x1 layers with a bias, Cout % 256 == 0
+    and K >= 512 at stride 1 / K >= 256 at stride 2) against torch fp32 - and bit for bit against conv_igemm2 / conv_big, the kernels
+    the same layers ran on before and still run on without a bias: the choice between them must never show in a frame's result.  Any
+    number of workgroups walks the same pixels to the same bits."""
+    import proben_amd
+    N, H, W, Cin, Cout, relu = case[:6]
+    stride = case[6] if len(case) > 6 else 1
+    hooks = proben_amd._lib.test_hooks()
+    g = torch.Generator(device="cpu").manual_seed(21)
+    x = torch.randn(N, H, W, Cin, generator=g).cuda().half().relu()
+    w = (torch.randn(Cout, 1, 1, Cin, generator=g) / Cin ** 0.5).cuda().half()
+    b = torch.randn(Cout, generator=g).cuda()
+    Mo = N * ((H - 1) // stride + 1) * ((W - 1) // stride + 1)
+    assert L.conv_variant_name(Mo, Cout, 1, Cin, stride=stride, in_pixels=N * H * W) == "conv1x1_ring_kernel"
+    ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).float(), w.permute(0, 3, 1, 2).float(), b, stride=stride)
+    ref = (ref.relu() if relu else ref).permute(0, 2, 3, 1)
+    try:
+        hooks.pe_test_set_conv_policy(9, 1)                      # round-4 dispatch: conv_igemm2 / conv_big
+        old = L.conv2d_nhwc(x, w, b, kernel=1, stride=stride, relu=relu)
+        hooks.pe_test_set_conv_policy(L.DEFAULT_CONV_POLICY, 1)
+        out = torch.full_like(old, float("nan"))
+        L.conv2d_nhwc(x, w, b, kernel=1, stride=stride, relu=relu, out=out)
+        outs = [out.clone()]
+        for wgs in (8, 64, 248):
+            hooks.pe_test_set_ring_wgs(wgs)
+            o = torch.full_like(old, float("nan"))
+            L.conv2d_nhwc(x, w, b, kernel=1, stride=stride, relu=relu, out=o)
+            outs.append(o)
+        torch.cuda.synchronize()
+    finally:
+        hooks.pe_test_set_ring_wgs(256)
+        hooks.pe_test_set_conv_policy(L.DEFAULT_CONV_POLICY, 1)
+    torch.testing.assert_close(out.float(), ref, rtol=4e-3, atol=4e-3)
+    for o in outs:
+        assert torch.equal(o, old)
+
+
 @pytest.mark.parametrize("case", [(16, 100, 128, 128, 128, 3, 1, True, 0), (9, 99, 131, 64, 256, 3, 1, False, 0),
                                   (2, 25, 32, 256, 256, 3, 1, True, 0), (3, 40, 50, 64, 64, 3, 1, True, 0)])
 def test_conv3x3_weight_double_buffered_kernel(L, case):
