@@ -76,7 +76,9 @@ def main(cmd=None):
     torch.cuda.synchronize()
     import hashlib
     digest = hashlib.sha256(tuner.head.flat.master.detach().cpu().numpy().tobytes()).hexdigest()[:16]
-    print(json.dumps({"rank": rank, "weights_sha": digest, "last_loss_cls": round(log[-1]["loss_cls"], 6)}), flush=True)    # every rank: DDP keeps them equal
+    backend = torch.distributed.get_backend() if comm.is_distributed() else "none"      # "nccl" = RCCL: what two visible devices must give
+    print(json.dumps({"rank": rank, "weights_sha": digest, "last_loss_cls": round(log[-1]["loss_cls"], 6), "backend": backend,
+                      "reducer_on_device": bool(tuner.reducer.backend_is_device)}), flush=True)    # every rank: DDP keeps the weights equal
     if comm.is_main_process():
         dt = time.time() - t0
         print(json.dumps({"steps": args.steps, "world_size": world, "images_per_s": round(args.steps * args.images_per_step * world / dt, 1)}))

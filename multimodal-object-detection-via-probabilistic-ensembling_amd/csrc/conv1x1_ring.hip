@@ -169,6 +169,7 @@ __device__ __forceinline__ void rg_compute(float16v (&acc)[2][2], const unsigned
     mma(1);
 }
 
+template <bool RELU>      // compile-time: a run-time flag costs a v_cndmask per output element in a VALU-bound epilogue
 __global__ __launch_bounds__(RG_THREADS) void conv1x1_ring_kernel(RingArgs a) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     typedef __attribute__((address_space(3))) unsigned char lds_byte;
@@ -359,7 +360,7 @@ __global__ __launch_bounds__(RG_THREADS) void conv1x1_ring_kernel(RingArgs a) {
                         const float b0 = fkh ? bs.v[j * 4 + 2][e] : bs.v[j * 4 + 0][e];
                         const float b1 = fkh ? bs.v[j * 4 + 3][e] : bs.v[j * 4 + 1][e];
                         float x0 = acc[i][j][e] + b0, x1 = acc[i][j][e + 8] + b1;
-                        if (a.relu) { x0 = pe::relu_nan(x0); x1 = pe::relu_nan(x1); }
+                        if (RELU) { x0 = pe::relu_nan(x0); x1 = pe::relu_nan(x1); }
                         h0[e] = (_Float16)x0;
                         h1[e] = (_Float16)x1;
                     }
@@ -413,8 +414,13 @@ int conv1x1_ring_launch(const void* in, const void* wgt, const float* bias, void
     // Cout > 256: tiles_n workgroups per run when every run still has at least one m-tile's worth of blocks
     int grid = a.nblk < wgs ? a.nblk : wgs;
     if (a.tiles_n > 1 && wgs % (8 * a.tiles_n) == 0 && a.nblk >= wgs / a.tiles_n) grid = wgs;
-    PE_ENSURE_LDS(conv1x1_ring_kernel, (size_t)RG_LDS, "pe_conv2d_nhwc_f16(1x1 ring)");
-    hipLaunchKernelGGL(conv1x1_ring_kernel, dim3(grid), dim3(RG_THREADS), (size_t)RG_LDS, st, a);
+    if (relu) {
+        PE_ENSURE_LDS(conv1x1_ring_kernel<true>, (size_t)RG_LDS, "pe_conv2d_nhwc_f16(1x1 ring)");
+        hipLaunchKernelGGL(conv1x1_ring_kernel<true>, dim3(grid), dim3(RG_THREADS), (size_t)RG_LDS, st, a);
+    } else {
+        PE_ENSURE_LDS(conv1x1_ring_kernel<false>, (size_t)RG_LDS, "pe_conv2d_nhwc_f16(1x1 ring)");
+        hipLaunchKernelGGL(conv1x1_ring_kernel<false>, dim3(grid), dim3(RG_THREADS), (size_t)RG_LDS, st, a);
+    }
     PE_CHECK_LAUNCH("pe_conv2d_nhwc_f16(1x1 ring)");
     return PE_OK;
 }

@@ -160,6 +160,10 @@ def test_world_size_2_box_head_training_keeps_the_ranks_in_step():
         assert len(rows) == world, (p.stdout[-1500:], p.stderr[-1500:])
         runs[world] = {r["rank"]: r for r in rows}
     two = runs[2]
+    if torch.cuda.device_count() >= 2:      # two devices: the ranks MUST be on RCCL and the reducer on its async device all-reduce branch
+        assert all(r["backend"] == "nccl" and r["reducer_on_device"] for r in two.values()), two
+    else:                                   # one device shared by two ranks: RCCL refuses that, the collectives are staged over gloo
+        assert all(r["backend"] == "gloo" and not r["reducer_on_device"] for r in two.values()), two
     assert two[0]["weights_sha"] == two[1]["weights_sha"]
     assert two[0]["last_loss_cls"] != two[1]["last_loss_cls"]
     assert runs[1][0]["weights_sha"] != two[0]["weights_sha"]
