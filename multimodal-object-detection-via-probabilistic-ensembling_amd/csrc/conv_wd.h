@@ -95,6 +95,18 @@ __host__ __device__ inline int k3x3_of_kseq(int kseq, int Cin, int e) {
 // tail_cout outputs of conv3 in chunks of 64 - t fragments from LDS, conv3 weights L2 -> VGPR in fragment order, no barrier in
 // the whole phase -, adds the shortcut (one channel quarter per 4 K-steps, requested 3 K-steps ahead, 16 registers live) and ReLU, and stores.
 // Neither t nor a second launch's re-read of it touches HBM, and the latency-bound 1x1 kernel is gone from the block.
+typedef float float8v __attribute__((ext_vector_type(8)));
+// 2 x 16 consecutive floats at two wave-uniform addresses through the scalar cache, one wait
+__device__ __forceinline__ void wd_sload4(float8v& a0, float8v& a1, float8v& b0, float8v& b1, const float* pa, const float* pb) {
+    auto uni = [](const float* p) {
+        const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+        return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+    };
+    asm volatile("s_load_dwordx8 %0, %4, 0x0\n\ts_load_dwordx8 %1, %4, 0x20\n\ts_load_dwordx8 %2, %5, 0x0\n\ts_load_dwordx8 %3, %5, 0x20\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&s"(a0), "=&s"(a1), "=&s"(b0), "=&s"(b1)
+                 : "s"(uni(pa)), "s"(uni(pb)));
+}
 template <int WM, int WN, int TPX, int DEPTH, int ABL = 0, int HEAD = 0>
 __global__ __launch_bounds__(64 * WM * WN, (TPX <= 4 ? 2 : 1)) void conv3x3_wd_kernel(pe::ConvWdArgs a) {
     constexpr int THREADS = 64 * WM * WN;
@@ -385,14 +397,21 @@ __global__ __launch_bounds__(64 * WM * WN, (TPX <= 4 ? 2 : 1)) void conv3x3_wd_k
         for (int c = 0; c < NCH; ++c) {
             const int ob = wn * (NCH * 64) + c * 64 + (lane >> 5) * 32;    // this lane's 32 consecutive outputs of the chunk
             {
-                const float* bp = a.tail_b + ob;
+                // Round 5: the chunk's bias through the SCALAR cache (the address of the wave's 64 outputs is uniform; a lane picks its
+                // 32 by lane >> 5).  As vector loads these were the YOUNGEST vector-memory operations at the chunk's first MFMA, so waiting
+                // for them was `vmcnt(0)`: every chunk opened by draining the previous chunk's 16 line stores (write acknowledgements under
+                // full HBM load) and the prefetched shortcut quarter.  Without them the first wait is a counted one and the stores stay in flight.
+                // Same bits; -1..-5 % per launch, +0.2 % in the pipeline (profiles/r05_tail_bias_ab.txt; the A/B hook and the old form are gone).
+                const float* bw = a.tail_b + wn * (NCH * 64) + c * 64;
 #pragma unroll
                 for (int blk = 0; blk < 2; ++blk) {
+                    float8v s0, s1, s2, s3;      // outputs [blk * 16, +16) of lane half 0 (s0, s1) and of lane half 1 (s2, s3)
+                    wd_sload4(s0, s1, s2, s3, bw + blk * 16, bw + 32 + blk * 16);
                     float16v b;
 #pragma unroll
-                    for (int r4 = 0; r4 < 4; ++r4) {
-                        const float4 v = *reinterpret_cast<const float4*>(bp + blk * 16 + r4 * 4);
-                        b[r4 * 4 + 0] = v.x; b[r4 * 4 + 1] = v.y; b[r4 * 4 + 2] = v.z; b[r4 * 4 + 3] = v.w;
+                    for (int e = 0; e < 8; ++e) {
+                        b[e] = (lane >> 5) ? s2[e] : s0[e];
+                        b[e + 8] = (lane >> 5) ? s3[e] : s1[e];
                     }
 #pragma unroll
                     for (int i = 0; i < TPX; ++i) acc[blk][i] = b;

@@ -130,4 +130,3 @@ extern "C" int pe_bottleneck_tail_wd_f16(const void* input, const void* packed_w
     PE_CHECK_LAUNCH("pe_bottleneck_tail_wd_f16");
     return PE_OK;
 }
-
