@@ -57,6 +57,31 @@ __device__ __forceinline__ half8 bload(const __amdgpu_buffer_rsrc_t& r, unsigned
     return __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
 
+typedef float float8v __attribute__((ext_vector_type(8)));
+// 2 x 16 consecutive floats at two wave-uniform addresses through the scalar cache, one wait (the twin of conv_wd.h's wd_sload4)
+__device__ __forceinline__ void b64_sload4(float8v& a0, float8v& a1, float8v& b0, float8v& b1, const float* pa, const float* pb) {
+    auto uni = [](const float* p) {
+        const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+        return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+    };
+    asm volatile("s_load_dwordx8 %0, %4, 0x0\n\ts_load_dwordx8 %1, %4, 0x20\n\ts_load_dwordx8 %2, %5, 0x0\n\ts_load_dwordx8 %3, %5, 0x20\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&s"(a0), "=&s"(a1), "=&s"(b0), "=&s"(b1)
+                 : "s"(uni(pa)), "s"(uni(pb)));
+}
+// the 16 bias values of accumulator block `blk` of this lane (lane half h owns channels [32 h + 16 blk, +16) of the 64 at `p`)
+__device__ __forceinline__ float16v b64_bias16(const float* p, int blk, int h) {
+    float8v s0, s1, s2, s3;
+    b64_sload4(s0, s1, s2, s3, p + blk * 16, p + 32 + blk * 16);
+    float16v b;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        b[e] = h ? s2[e] : s0[e];
+        b[e + 8] = h ? s3[e] : s1[e];
+    }
+    return b;
+}
+
 template <bool SC, bool NEXT>
 __global__ __launch_bounds__(256, 2) void bneck64_kernel(B64Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -248,14 +273,14 @@ __global__ __launch_bounds__(256, 2) void bneck64_kernel(B64Args a) {
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk) {
             float16v b;
+            // Round 5: the chunk's biases through the scalar cache.  As vector loads they were the youngest vector-memory operations at
+            // the chunk's first MFMA: waiting for them drained the previous chunk's line stores and the prefetched shortcut (`vmcnt(0)`) in
+            // a kernel that is HBM-bound.  Same bits; -2..-4 % on the two NEXT forms, +1 % on the last block's (profiles/r05_b64_bias_ab.txt).
+            b = b64_bias16(a.b3 + c * 64, blk, h);
+            if (SC) {
+                const float16v u = b64_bias16(a.bsc + c * 64, blk, h);
 #pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-                float4 v = *reinterpret_cast<const float4*>(a.b3 + c * 64 + h * 32 + blk * 16 + r4 * 4);
-                if (SC) {
-                    const float4 u = *reinterpret_cast<const float4*>(a.bsc + c * 64 + h * 32 + blk * 16 + r4 * 4);
-                    v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
-                }
-                b[r4 * 4 + 0] = v.x; b[r4 * 4 + 1] = v.y; b[r4 * 4 + 2] = v.z; b[r4 * 4 + 3] = v.w;
+                for (int e = 0; e < 16; ++e) b[e] += u[e];
             }
             acc3[blk][0] = b; acc3[blk][1] = b;
         }

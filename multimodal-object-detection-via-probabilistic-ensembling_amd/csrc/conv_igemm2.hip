@@ -85,6 +85,10 @@ __global__ __launch_bounds__(BM * 2, BM == 128 ? (STAGES == 1 ? 3 : 2) : (STAGES
     const unsigned char* lb = smem + A_BYTES + (wn * WN + frow) * ROW_B;
 
     const int nk = a.K / BK;
+    const Bias8 bias8 = preload_bias8<BN>(a, n0, tid);
+    // pass 0 of the residual under the whole K-loop: same-box A/B -6 % on res3 conv3 (K = 128: the tile is all epilogue), +-1..3 % on
+    // the others, +0.25 % in the pipeline (profiles/r05_res_prefetch_ab.txt)
+    const ResVecs<BN, THREADS> res0 = load_res<BN, THREADS>(a, m0, n0, tid, 0);
     // LDS-DMA of K-step kt into LDS stage `st`: global -> LDS, no VGPR round trip
     auto dma = [&](int kt, int st) {
         const int k0 = kt * BK;
@@ -151,7 +155,7 @@ __global__ __launch_bounds__(BM * 2, BM == 128 ? (STAGES == 1 ? 3 : 2) : (STAGES
         }
     }
 
-    epilogue<BM, BN, THREADS>(a, acc, smem, m0, n0, tid, lane, wm, wn);
+    epilogue<BM, BN, THREADS>(a, acc, smem, m0, n0, tid, lane, wm, wn, bias8, &res0);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -295,7 +299,8 @@ __global__ __launch_bounds__(BM * 2, BM == 128 ? 3 : 4) void conv3x3rb_kernel(Co
             __syncthreads();  // next weight tile landed; this tap's LDS reads retired
         }
     }
-    epilogue<BM, BN, THREADS>(a, acc, smem, m0, n0, tid, lane, wm, wn);
+    // (128 registers at 256-row tiles: no room to carry the bias or a residual through the loop - both are requested here)
+    epilogue<BM, BN, THREADS>(a, acc, smem, m0, n0, tid, lane, wm, wn, preload_bias8<BN>(a, n0, tid), nullptr);
 }
 
 template <int BM, int BN>

@@ -395,7 +395,6 @@ __global__ __launch_bounds__(64 * WM * WN, (TPX <= 4 ? 2 : 1)) void conv3x3_wd_k
         };
         r_load(0, 0);
         for (int c = 0; c < NCH; ++c) {
-            const int ob = wn * (NCH * 64) + c * 64 + (lane >> 5) * 32;    // this lane's 32 consecutive outputs of the chunk
             {
                 // Round 5: the chunk's bias through the SCALAR cache (the address of the wave's 64 outputs is uniform; a lane picks its
                 // 32 by lane >> 5).  As vector loads these were the YOUNGEST vector-memory operations at the chunk's first MFMA, so waiting

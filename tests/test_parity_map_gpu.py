@@ -9,9 +9,9 @@ writes its record for profiles/ (this file only asserts).
 
 What the numbers mean (profiles/r04_map_parity.json, profiles/r04_map_fp16_ablation.json): on ONE 256-frame set the AP
 figures of the two detectors differ by a few tenths of a point with either sign - the ORACLE with fp16 rounding emulated at the device's
-storage points scatters the same way (+0.22 / +0.32 / +0.31 on the fixture set) - and over five disjoint sets (1 280 frames, 7 585
-objects) the differences average out: mean dAP -0.04 (std over sets 0.19), dAP50 -0.07 (0.29), dAP75 -0.01 (0.27).  north_star's 0.1
-point holds for the mean, not for a single 256-frame set; the tests below assert exactly that."""
+storage points scatters the same way (+0.22 / +0.32 / +0.31 on the fixture set) - and over TEN disjoint sets (round 5: 2 560 frames,
+15 184 objects; profiles/r05_map_flips.json) the differences average out: mean dAP -0.05 (std over sets 0.18), dAP50 -0.08 (0.24),
+dAP75 -0.03 (0.38).  north_star's 0.1 point holds for the mean, not for a single 256-frame set; the tests below assert exactly that."""
 import os
 
 import numpy as np
@@ -31,32 +31,42 @@ def record(golden_dir):
     return _REC["rec"]
 
 
+# per-set bounds = |mean| + 3 sigma of the per-set deltas over the ten evaluation sets (profiles/r05_map_flips.json: mean / std
+# AP -0.05 / 0.18, AP50 -0.08 / 0.24, AP75 -0.03 / 0.38, APm +0.05 / 0.34, APl -0.05 / 0.14), rounded up to a tenth
+PER_SET_BOUND = {"AP": 0.6, "AP50": 0.9, "AP75": 1.2, "APm": 1.1, "APl": 0.5}
+# bounds of the MEAN over the sets = 3 standard errors (0.057 / 0.077 / 0.12 / 0.11 / 0.046)
+MEAN_BOUND = {"AP": 0.2, "AP50": 0.25, "AP75": 0.4, "APm": 0.35, "APl": 0.15}
+
+
 def test_map_of_hip_and_oracle_against_the_same_ground_truth(golden_dir):
-    """Regression bound: every AP figure of every evaluation set within 1.0 point of the oracle's (measured: at most 0.59), the mean
-    over the sets within 0.3 (measured: at most 0.08), the detection count within 1 %, and no systematic box shift (signed mean
-    offset of the matched pairs < 0.1 px).  Measured: profiles/r04_map_parity.json - the deltas change sign from set to set and
-    with the rounding realisation (r03 / r04 kernels on the same set), as noise does and a bias does not."""
+    """Regression bound, set from the measured distribution instead of round 4's flat 1.0: every AP figure of every
+    evaluation set within mean + 3 sigma of the ten-set record (PER_SET_BOUND), the mean over the sets within 3 standard errors
+    (MEAN_BOUND), the detection count within 1 %, and no systematic box shift (signed mean offset of the matched pairs < 0.1 px).
+    What the differences ARE is in profiles/r05_map_flips.json (scripts/map_parity_diff.py): 89 % of the unmatched detections are
+    final-NMS winner flips between saturated, near-tied scores - they carry 3.4-4.5 AP points on each side and cancel -, 3 % threshold
+    flips and 8 % missing proposals carry <= 0.04."""
     rec = record(golden_dir)
     z, _, _, gts = load_fixture(golden_dir)
     first = next(iter(rec["sets"].values()))
     np.testing.assert_allclose([first["oracle"][n] / 100 for n in NAMES], z["oracle_stats"][:6], rtol=0, atol=1e-12)   # the fixture's own table re-derives
     assert first["oracle"]["AP50"] > 50, "the fitted heads must give a meaningful detector (AP50 of the oracle > 50)"
     for name, s in rec["sets"].items():
-        for n in ("AP", "AP50", "AP75", "APm", "APl"):
-            assert abs(s["delta"][n]) <= 1.0, (name, n, s["delta"])
+        for n, bound in PER_SET_BOUND.items():
+            assert abs(s["delta"][n]) <= bound, (name, n, s["delta"])
         assert abs(s["hip_detections"] - s["oracle_detections"]) <= 0.01 * s["oracle_detections"], name
-    for n in ("AP", "AP50", "AP75", "APm", "APl"):
-        assert abs(rec["delta_mean"][n]) <= 0.3, (n, rec["delta_mean"])
+    for n, bound in MEAN_BOUND.items():
+        assert abs(rec["delta_mean"][n]) <= bound, (n, rec["delta_mean"])
     off = rec["matched_pairs_signed"]["box_offset_mean_px"]
-    assert max(abs(v) for v in off.values()) < 0.1, off      # measured +0.048 px on x1 (30 sigma over 28 605 pairs), +0.026 on y1 - and the oracle with fp16 rounding emulated shows the same +0.042 / +0.024: an fp16 effect, not a kernel one
+    assert max(abs(v) for v in off.values()) < 0.1, off      # measured +0.048 px on x1, +0.026 on y1 - and the oracle with fp16 rounding emulated shows the same +0.042 / +0.024: an fp16 effect, not a kernel one
 
 
 def test_map_within_north_star_tolerance(golden_dir):
-    """north_star: mAP within 1e-3 (0.1 point) of the reference's.  Asserted on the MEAN over the five evaluation sets (1 280 frames):
-    measured dAP -0.04, dAP50 -0.07, dAP75 -0.01 with a standard error of 0.09-0.13 - consistent with zero, inside the tolerance.  A
-    single 256-frame set cannot resolve 0.1 point (std over sets 0.19-0.29): that is the sets' granularity, not the detector's."""
+    """north_star: mAP within 1e-3 (0.1 point) of the reference's.  Asserted on the MEAN over the TEN evaluation sets (2 560 frames,
+    15 184 objects): measured dAP -0.05, dAP50 -0.08, dAP75 -0.03 with standard errors of 0.06 / 0.08 / 0.12 (pooled as one dataset:
+    -0.03 / -0.08 / +0.02) - consistent with zero, inside the tolerance.  A single 256-frame set cannot resolve 0.1 point (std over sets
+    0.18-0.38): that is the sets' granularity, not the detector's."""
     rec = record(golden_dir)
-    assert rec["n_sets"] >= 5, "the multi-set fixture (tests/golden/pseudo_heads_r101_sets.npz) is missing"
+    assert rec["n_sets"] >= 10, "the multi-set fixture (tests/golden/pseudo_heads_r101_sets.npz, ten sets) is missing"
     for n in ("AP", "AP50", "AP75"):
         assert abs(rec["delta_mean"][n]) <= NORTH_STAR_POINTS, (n, rec["delta_mean"], rec["delta_std"])
 
