@@ -286,6 +286,11 @@ __global__ __launch_bounds__(THREADS, 1) void conv3x3_wd9_kernel(pe::ConvWdArgs 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
+    float4 hb0 = make_float4(0.f, 0.f, 0.f, 0.f), hb1 = hb0;
+    if constexpr (EP == 2) {
+        hb0 = *reinterpret_cast<const float4*>(a.head_b + (tid & 1) * 8);
+        hb1 = *reinterpret_cast<const float4*>(a.head_b + (tid & 1) * 8 + 4);
+    }
     half8 pf[2][TPX];
     int cur = 0;
 #pragma unroll
@@ -397,7 +402,7 @@ __global__ __launch_bounds__(THREADS, 1) void conv3x3_wd9_kernel(pe::ConvWdArgs 
                     {
                         const int px = tid >> 1, q = tid & 1;
                         const int m = m0 + hf * 128 + px;
-                        float4 s0 = *reinterpret_cast<const float4*>(a.head_b + q * 8), s1 = *reinterpret_cast<const float4*>(a.head_b + q * 8 + 4);
+                        float4 s0 = hb0, s1 = hb1;      // head bias: loaded once per workgroup (a load here would wait out the next tile's slab DMAs)
 #pragma unroll
                         for (int w = 0; w < 4; ++w) {
                             const float4 x0 = *reinterpret_cast<const float4*>(red + (w * 128 + px) * 16 + q * 8);
