@@ -68,7 +68,7 @@ def parse(argv=None):
     ap.add_argument("--serial-detectors", action="store_true", help="run the detectors back to back on one stream")
     ap.add_argument("--wd9-wgs", type=int, default=0, help="A/B: workgroups of the persistent pure 3x3 kernel (0 = the library's default)")
     ap.add_argument("--no-power", action="store_true", help="do not poll rocm-smi for board power during the timed region")
-    ap.add_argument("--conv-policy", type=int, default=-1, help="A/B: tile_bits of pe_test_set_conv_policy (csrc/test_hooks.h; default 73)")
+    ap.add_argument("--conv-policy", type=int, default=-1, help="A/B: tile_bits of pe_test_set_conv_policy (csrc/test_hooks.h; default 329)")
     ap.add_argument("--roi-sort", type=int, default=1, help="0: ROIAlign takes the proposals in RPN order (A/B; identical results)")
     ap.add_argument("--wd9-mode", type=int, default=-1,
                     help="A/B (csrc/test_hooks.h): 0 = two-wave weights-direct kernels only (csrc/conv_wd.h), 1 = persistent one-wave-per-SIMD "

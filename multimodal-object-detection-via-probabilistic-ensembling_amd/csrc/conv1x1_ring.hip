@@ -53,6 +53,9 @@ struct RingArgs {
     int nblk;      // 32-pixel blocks in the launch
     int tiles_n;   // Cout / 256
     int stride, H, W, Ho, Wo;
+    const _Float16* res;      // residual (conv_igemm2's modes): 1 = [M, Cout] like the output, 2 = FPN top-down: [N, resH, resW, Cout], pixel (oh >> 1, ow >> 1)
+    int res_mode, resH, resW;
+    unsigned res_bytes;
     unsigned in_bytes;           // stride 2 (shortcut convolutions): output pixel (n, oh, ow) reads input pixel (n, 2 oh, 2 ow) of [N, H, W, K]
     int abl;       // measurement builds (results wrong): 1 = no pixel DMA, 2 = no weight DMA, 4 = no ds_read / MFMA, 8 = no stores,
                    // 16 = pixel slabs fetched as if the input were K-chunk-major [K / 64][M][64] (contiguous 16 KiB per slab)
@@ -169,7 +172,7 @@ __device__ __forceinline__ void rg_compute(float16v (&acc)[2][2], const unsigned
     mma(1);
 }
 
-template <bool RELU>      // compile-time: a run-time flag costs a v_cndmask per output element in a VALU-bound epilogue
+template <bool RELU, bool RES>      // compile-time: a run-time flag costs a v_cndmask per output element in a VALU-bound epilogue; RES: with a residual (its 32 registers only where needed)
 __global__ __launch_bounds__(RG_THREADS) void conv1x1_ring_kernel(RingArgs a) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     typedef __attribute__((address_space(3))) unsigned char lds_byte;
@@ -312,6 +315,7 @@ __global__ __launch_bounds__(RG_THREADS) void conv1x1_ring_kernel(RingArgs a) {
     const unsigned char* la = smem + (wm * 64 + frow) * ROW_B;
     const unsigned char* lb = smem + RG_BBASE + (wn * 64 + prow) * ROW_B;
     const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, a.M * a.out_stride * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.res ? a.res : a.in), 0, a.res ? (int)a.res_bytes : 0, 0x00020000);
 
     float16v acc[2][2];
 #pragma unroll
@@ -321,6 +325,35 @@ __global__ __launch_bounds__(RG_THREADS) void conv1x1_ring_kernel(RingArgs a) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+    // Residual of the tile in ACCUMULATOR layout (a lane's 16 consecutive channels of its pixel = two 16-byte pieces per accumulator tile; loads
+    // tolerate that pattern - the L1 merges a lane's pieces, DESIGN 7.5 - stores do not), requested under the tile's last K-step like the bias.
+    half8 rv[RES ? 2 : 1][2][2];
+    auto res_issue = [&](int nn, int mtile) {
+        const int mrow0 = (b0 + 4 * mtile) * 32;
+        const int nbt_ = nb - 4 * mtile;
+        int vrows = (nbt_ < 4 ? nbt_ : 4) * 32;
+        vrows = vrows < a.M - mrow0 ? vrows : a.M - mrow0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = wm * 64 + i * 32 + frow, m = mrow0 + row;
+            unsigned off = RG_OOB;
+            if (row < vrows) {
+                if (a.res_mode == 1) {
+                    off = (unsigned)m * (unsigned)a.Cout * 2u;
+                } else {
+                    const int ow = m % a.Wo, t = m / a.Wo;
+                    const int oh = t % a.Ho, im = t / a.Ho;
+                    off = (unsigned)((im * a.resH + (oh >> 1)) * a.resW + (ow >> 1)) * (unsigned)a.Cout * 2u;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const unsigned co = (unsigned)(nn * RG_BN + wn * 64 + j * 32 + fkh * 16) * 2u;
+                rv[i][j][0] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rres, off == RG_OOB ? RG_OOB : off + co, 0, 0));
+                rv[i][j][1] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rres, off == RG_OOB ? RG_OOB : off + co + 16, 0, 0));
+            }
+        }
+    };
     RgBias bs;       // live from the tile's last K-step to its epilogue only (a launch without a bias stays on conv_igemm2: conv2_dispatch)
     int sa = 0, sb = 0, ks = 0, n = n0, mt = 0;
     for (int s = 0; s < S; ++s) {
@@ -329,7 +362,10 @@ __global__ __launch_bounds__(RG_THREADS) void conv1x1_ring_kernel(RingArgs a) {
         const int mine = nbt - 2 * wm;               // ... of which this wave owns min(2, mine)
         const unsigned char* pa = la + sa * RG_ASTAGE_B;
         const unsigned char* pb = lb + sb * RG_BSTAGE_B;
-        if (ks == nk - 1) rg_bias_issue(bs, a.bias + n * RG_BN + wn * 64);      // in flight under the tile's last K-step
+        if (ks == nk - 1) {
+            rg_bias_issue(bs, a.bias + n * RG_BN + wn * 64);      // in flight under the tile's last K-step
+            if constexpr (RES) res_issue(n, mt);
+        }
         // ONE code path: a wave that owns one block of a partial tile multiplies the loader's zeros for the other (a second, 1-block
         // path makes the accumulators PHI values: 32 v_mov per K-step behind the MFMAs - measured +9 us per launch); a wave that owns
         // none skips the step, which leaves its SIMD to the other wave: a partial tile costs about half a tile either way
@@ -360,6 +396,10 @@ __global__ __launch_bounds__(RG_THREADS) void conv1x1_ring_kernel(RingArgs a) {
                         const float b0 = fkh ? bs.v[j * 4 + 2][e] : bs.v[j * 4 + 0][e];
                         const float b1 = fkh ? bs.v[j * 4 + 3][e] : bs.v[j * 4 + 1][e];
                         float x0 = acc[i][j][e] + b0, x1 = acc[i][j][e + 8] + b1;
+                        if constexpr (RES) {      // (not unconditionally: -0.f + 0.f would change a sign bit)
+                            x0 += (float)rv[i][j][0][e];
+                            x1 += (float)rv[i][j][1][e];
+                        }
                         if (RELU) { x0 = pe::relu_nan(x0); x1 = pe::relu_nan(x1); }
                         h0[e] = (_Float16)x0;
                         h1[e] = (_Float16)x1;
@@ -400,13 +440,15 @@ bool conv1x1_ring_eligible(int M, int K, int Cout, int cout_store, int out_strid
            (long long)Cout * K * 2 < (1ll << 31) && (long long)M * out_stride * 2 < (1ll << 31);
 }
 
-int conv1x1_ring_launch(const void* in, const void* wgt, const float* bias, void* out, int N, int H, int W, int Ho, int Wo, int stride, int M,
-                        int K, int Cout, int out_stride, int relu, hipStream_t st) {
+int conv1x1_ring_launch(const void* in, const void* wgt, const float* bias, const void* res, int res_mode, int resH, int resW, void* out, int N,
+                        int H, int W, int Ho, int Wo, int stride, int M, int K, int Cout, int out_stride, int relu, hipStream_t st) {
     RingArgs a{};
     a.in = (const _Float16*)in; a.wgt = (const _Float16*)wgt; a.bias = bias; a.out = (_Float16*)out;
     a.M = M; a.K = K; a.Cout = Cout; a.out_stride = out_stride; a.relu = relu;
     a.stride = stride; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo;
     a.in_bytes = (unsigned)((long long)N * H * W * K * 2);
+    a.res = res_mode ? (const _Float16*)res : nullptr; a.res_mode = res_mode; a.resH = resH; a.resW = resW;
+    a.res_bytes = res_mode == 1 ? (unsigned)((long long)M * Cout * 2) : res_mode == 2 ? (unsigned)((long long)N * resH * resW * Cout * 2) : 0u;
     a.nblk = pe::ceil_div(M, 32);
     a.tiles_n = Cout / RG_BN;
     a.abl = g_ring_abl.load(std::memory_order_relaxed);
@@ -414,13 +456,16 @@ int conv1x1_ring_launch(const void* in, const void* wgt, const float* bias, void
     // Cout > 256: tiles_n workgroups per run when every run still has at least one m-tile's worth of blocks
     int grid = a.nblk < wgs ? a.nblk : wgs;
     if (a.tiles_n > 1 && wgs % (8 * a.tiles_n) == 0 && a.nblk >= wgs / a.tiles_n) grid = wgs;
-    if (relu) {
-        PE_ENSURE_LDS(conv1x1_ring_kernel<true>, (size_t)RG_LDS, "pe_conv2d_nhwc_f16(1x1 ring)");
-        hipLaunchKernelGGL(conv1x1_ring_kernel<true>, dim3(grid), dim3(RG_THREADS), (size_t)RG_LDS, st, a);
-    } else {
-        PE_ENSURE_LDS(conv1x1_ring_kernel<false>, (size_t)RG_LDS, "pe_conv2d_nhwc_f16(1x1 ring)");
-        hipLaunchKernelGGL(conv1x1_ring_kernel<false>, dim3(grid), dim3(RG_THREADS), (size_t)RG_LDS, st, a);
-    }
+#define PE_RING_LAUNCH(RELU, RES)                                                                                     \
+    do {                                                                                                                  \
+        PE_ENSURE_LDS((conv1x1_ring_kernel<RELU, RES>), (size_t)RG_LDS, "pe_conv2d_nhwc_f16(1x1 ring)");                    \
+        hipLaunchKernelGGL((conv1x1_ring_kernel<RELU, RES>), dim3(grid), dim3(RG_THREADS), (size_t)RG_LDS, st, a);       \
+    } while (0)
+    if (relu && res_mode) PE_RING_LAUNCH(true, true);
+    else if (relu) PE_RING_LAUNCH(true, false);
+    else if (res_mode) PE_RING_LAUNCH(false, true);
+    else PE_RING_LAUNCH(false, false);
+#undef PE_RING_LAUNCH
     PE_CHECK_LAUNCH("pe_conv2d_nhwc_f16(1x1 ring)");
     return PE_OK;
 }

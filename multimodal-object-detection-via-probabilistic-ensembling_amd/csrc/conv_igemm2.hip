@@ -466,11 +466,12 @@ int launch2(const Conv2Args& a0, hipStream_t st) {
 
 namespace pe {
 bool conv1x1_ring_eligible(int M, int K, int Cout, int cout_store, int out_stride, long long in_pixels);
-int conv1x1_ring_launch(const void* in, const void* wgt, const float* bias, void* out, int N, int H, int W, int Ho, int Wo, int stride, int M,
-                        int K, int Cout, int out_stride, int relu, hipStream_t st);
-std::atomic<int> g_conv_tile256{73};  // bit 0: 256-row tiles for big 3x3 launches, bit 1: for big 1x1 launches, bit 2: two-stage 1x1 pipeline,
+int conv1x1_ring_launch(const void* in, const void* wgt, const float* bias, const void* res, int res_mode, int resH, int resW, void* out, int N,
+                        int H, int W, int Ho, int Wo, int stride, int M, int K, int Cout, int out_stride, int relu, hipStream_t st);
+std::atomic<int> g_conv_tile256{329};  // bit 0: 256-row tiles for big 3x3 launches, bit 1: for big 1x1 launches, bit 2: two-stage 1x1 pipeline,
                                       // bit 3: 256x256 two-stage kernel for long-K GEMMs, bit 4: ... for every eligible launch,
-                                      // bit 5 / 6: the persistent loader / consumer 1x1 kernel for res4 conv1 / for every eligible launch
+                                      // bit 5 / 6: the persistent loader / consumer 1x1 kernel for res4 conv1 / for every eligible residual-free launch,
+                                      // bit 8: ... for the residual layers as well
 std::atomic<int> g_conv3x3_reuse{1};  // 0: the generic per-tap 3x3 kernel instead of the kw-reuse one (A/B measurements)
 // called from pe_conv2d_nhwc_f16 (conv_igemm.hip) for the 1x1 / 3x3 cases
 int conv2_dispatch(const void* in, const void* wgt, const float* bias, const void* res, void* out, int N, int H, int W,
@@ -486,10 +487,13 @@ int conv2_dispatch(const void* in, const void* wgt, const float* bias, const voi
     // persistent loader / consumer 1x1 kernel (csrc/conv1x1_ring.hip; bit-identical results): policy bit 5 = the long-K, 256-output
     // layers (res4 conv1), bit 6 = every eligible launch (residual-free, fp16 out, bias, Cout % 256 == 0; K >= 512 at stride 1, the
     // stride-2 shortcut convolutions from K = 256).  Chosen by channel counts and stride only, never by the batch.
-    if ((policy & 96) && !mode3x3 && (stride == 1 || stride == 2) && !res_mode && !out_f32 && bias &&
-        ((policy & 64) ? K >= (stride == 1 ? 512 : 256) : (stride == 1 && K >= 1024 && Cout == 256)) &&
-        conv1x1_ring_eligible(M, K, Cout, cout_store, out_stride, (long long)N * H * W))
-        return conv1x1_ring_launch(in, wgt, bias, out, N, H, W, Ho, Wo, stride, M, K, Cout, out_stride, relu, st);
+    if ((policy & 96) && !mode3x3 && (stride == 1 || stride == 2) && !out_f32 && bias && conv1x1_ring_eligible(M, K, Cout, cout_store, out_stride, (long long)N * H * W)) {
+        bool take;
+        if (!(policy & 64)) take = stride == 1 && !res_mode && K >= 1024 && Cout == 256;
+        else if (res_mode) take = stride == 1 && K >= 128 && (policy & 256) && (long long)M * Cout * 2 < (1ll << 31);      // bit 8: the residual layers too (conv3 of res3 / res5, FPN laterals)
+        else take = K >= (stride == 1 ? 512 : 256);
+        if (take) return conv1x1_ring_launch(in, wgt, bias, res, res_mode, resH, resW, out, N, H, W, Ho, Wo, stride, M, K, Cout, out_stride, relu, st);
+    }
     // 256 x 256 two-stage kernel: fp16 output, whole 256-channel tiles, a grid that fills the 256 CUs
     // (measured r01: +24 % on the K = 12544 FC GEMM, neutral-to-negative on the convolutions -> long-K GEMMs only;
     //  policy bit 4 forces it everywhere it applies, for A/B runs)

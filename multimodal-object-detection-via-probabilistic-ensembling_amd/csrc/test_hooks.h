@@ -5,11 +5,12 @@
 extern "C" {
 #endif
 /* Kernel-selection policy of pe_conv2d_nhwc_f16 (process-global, relaxed atomics; affects launches issued afterwards).
- *   tile_bits (default 73 = 1|8|64):  1: 256-row block tiles (8 waves) for 3x3 launches with >= 512 such tiles   2: the same for 1x1
+ *   tile_bits (default 329 = 1|8|64|256):  1: 256-row block tiles (8 waves) for 3x3 launches with >= 512 such tiles   2: the same for 1x1
  *                                 4: two-stage pipeline in the generic 1x1 kernel   8: 256x256 two-stage kernel for long-K GEMMs
  *                                16: 256x256 kernel for every eligible launch
  *                                32: persistent loader / consumer 1x1 kernel (csrc/conv1x1_ring.hip) for K >= 1024, Cout == 256 (res4 conv1)
- *                                64: ... for every eligible 1x1 launch (stride 1, no residual, fp16 out, K >= 512, Cout % 256 == 0)
+ *                                64: ... for every eligible residual-free 1x1 launch (bias, fp16 out, Cout % 256 == 0; K >= 512 at stride 1, K >= 256 at stride 2)
+ *                               256: ... and for the stride-1 layers WITH a residual (both modes) from K = 128
  *   reuse3x3 (default 1): 1 = kw-reuse 3x3 kernel, 0 = generic per-tap 3x3 kernel */
 int pe_test_set_conv_policy(int tile_bits, int reuse3x3);
 /* Which generation of the weights-direct kernels takes a launch.  Bit mask (default 1 | 8; a negative mode restores the default;

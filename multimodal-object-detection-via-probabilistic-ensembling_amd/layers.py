@@ -372,7 +372,7 @@ def conv3x3_wd_rpn_head(x, packed, bias, packed_head, head_bias16, out=None):
     return out
 
 
-DEFAULT_CONV_POLICY = 73   # tile_bits of csrc/test_hooks.h pe_test_set_conv_policy the library starts with (tests restore it)
+DEFAULT_CONV_POLICY = 329   # tile_bits of csrc/test_hooks.h pe_test_set_conv_policy the library starts with (tests restore it)
 
 
 def conv_variant_name(M, Cout, kernel, K=0, *, stride=1, residual_mode=0, out_f32=False, has_bias=True, cout_store=0, out_stride=0, in_pixels=None):
@@ -382,7 +382,8 @@ def conv_variant_name(M, Cout, kernel, K=0, *, stride=1, residual_mode=0, out_f3
     if kernel == 7:
         return "conv_igemm_kernel<128, 64, 2>"          # 7x7 stem, register-staged kernel
     if kernel == 1:
-        ring = (stride in (1, 2) and residual_mode == 0 and not out_f32 and has_bias and K >= (512 if stride == 1 else 256) and Cout % 256 == 0
+        ring = (stride in (1, 2) and not out_f32 and has_bias and Cout % 256 == 0
+                and (K >= (512 if stride == 1 else 256) if residual_mode == 0 else (stride == 1 and K >= 128 and M * Cout * 2 < 2 ** 31))
                 and (cout_store or Cout) == Cout and (in_pixels or M) * K * 2 < 2 ** 31 and Cout * K * 2 < 2 ** 31 and M * (out_stride or Cout) * 2 < 2 ** 31)
         if ring:
             return "conv1x1_ring_kernel"                # persistent loader / consumer kernel (csrc/conv1x1_ring.hip)

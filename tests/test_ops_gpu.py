@@ -115,35 +115,48 @@ def test_conv_big_tile_kernel(L, case, policy):
     (8, 100, 128, 256, 512, False, 2),  # stride 2: res3's shortcut convolution (K = 256), two column tiles
     (3, 51, 65, 512, 1024, True, 2),    # stride 2 on odd sizes: 26 x 33 outputs, rows of a tile straddle image rows and images
     (2, 50, 64, 1024, 2048, False, 2),  # res5's shortcut: eight column tiles
+    (8, 100, 128, 128, 512, True, 1, 1),    # res3 conv3 + identity (residual mode 1), K = 128: two K-steps per tile
+    (3, 51, 65, 256, 256, False, 1, 2),     # FPN lateral + nearest-2x top-down map (mode 2) on odd sizes: 26 x 33 map
+    (4, 25, 32, 512, 2048, True, 1, 1),     # res5 conv3 + identity, eight column tiles
+    (16, 100, 128, 512, 256, True, 1, 2),   # p3 lateral at a size where tiles straddle image rows
 ])
 def test_conv1x1_ring_kernel_matches_torch_and_conv_igemm2_bit_for_bit(L, case):
-    """csrc/conv1x1_ring.hip (persistent loader / consumer 1x1 kernel, the default for residual-free 1x1 layers with a bias, Cout % 256 == 0
-    and K >= 512 at stride 1 / K >= 256 at stride 2) against torch fp32 - and bit for bit against conv_igemm2 / conv_big, the kernels
+    """csrc/conv1x1_ring.hip (persistent loader / consumer 1x1 kernel, the default for 1x1 layers with a bias and Cout % 256 == 0: residual-free
+    from K = 512 at stride 1 / K = 256 at stride 2, with a residual - both modes - from K = 128) against torch fp32 - and bit for bit against conv_igemm2 / conv_big, the kernels
     the same layers ran on before and still run on without a bias: the choice between them must never show in a frame's result.  Any
     number of workgroups walks the same pixels to the same bits."""
     import proben_amd
     N, H, W, Cin, Cout, relu = case[:6]
     stride = case[6] if len(case) > 6 else 1
+    res_mode = case[7] if len(case) > 7 else 0
     hooks = proben_amd._lib.test_hooks()
     g = torch.Generator(device="cpu").manual_seed(21)
     x = torch.randn(N, H, W, Cin, generator=g).cuda().half().relu()
     w = (torch.randn(Cout, 1, 1, Cin, generator=g) / Cin ** 0.5).cuda().half()
     b = torch.randn(Cout, generator=g).cuda()
-    Mo = N * ((H - 1) // stride + 1) * ((W - 1) // stride + 1)
-    assert L.conv_variant_name(Mo, Cout, 1, Cin, stride=stride, in_pixels=N * H * W) == "conv1x1_ring_kernel"
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    Mo = N * Ho * Wo
+    assert L.conv_variant_name(Mo, Cout, 1, Cin, stride=stride, residual_mode=res_mode, in_pixels=N * H * W) == "conv1x1_ring_kernel"
     ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).float(), w.permute(0, 3, 1, 2).float(), b, stride=stride)
+    res = None
+    if res_mode == 1:
+        res = torch.randn(N, Ho, Wo, Cout, generator=g).cuda().half()
+        ref = ref + res.permute(0, 3, 1, 2).float()
+    elif res_mode == 2:
+        res = torch.randn(N, (Ho + 1) // 2, (Wo + 1) // 2, Cout, generator=g).cuda().half()
+        ref = ref + torch.nn.functional.interpolate(res.permute(0, 3, 1, 2).float(), scale_factor=2, mode="nearest")[:, :, :Ho, :Wo]
     ref = (ref.relu() if relu else ref).permute(0, 2, 3, 1)
     try:
         hooks.pe_test_set_conv_policy(9, 1)                      # round-4 dispatch: conv_igemm2 / conv_big
-        old = L.conv2d_nhwc(x, w, b, kernel=1, stride=stride, relu=relu)
+        old = L.conv2d_nhwc(x, w, b, kernel=1, stride=stride, relu=relu, residual=res, residual_mode=res_mode)
         hooks.pe_test_set_conv_policy(L.DEFAULT_CONV_POLICY, 1)
         out = torch.full_like(old, float("nan"))
-        L.conv2d_nhwc(x, w, b, kernel=1, stride=stride, relu=relu, out=out)
+        L.conv2d_nhwc(x, w, b, kernel=1, stride=stride, relu=relu, residual=res, residual_mode=res_mode, out=out)
         outs = [out.clone()]
         for wgs in (8, 64, 248):
             hooks.pe_test_set_ring_wgs(wgs)
             o = torch.full_like(old, float("nan"))
-            L.conv2d_nhwc(x, w, b, kernel=1, stride=stride, relu=relu, out=o)
+            L.conv2d_nhwc(x, w, b, kernel=1, stride=stride, relu=relu, residual=res, residual_mode=res_mode, out=o)
             outs.append(o)
         torch.cuda.synchronize()
     finally:
