@@ -67,3 +67,43 @@ def test_two_wave_weights_direct_kernels_fit_two_per_simd_without_scratch(tmp_pa
         m = re.search(r"\.amdhsa_next_free_vgpr (\d+)", body)
         assert m and int(m.group(1)) <= 256, name
     assert seen >= 3, "pure, fused-head and fused-tail instantiations expected"
+
+
+def test_ring_kernel_fits_three_waves_per_simd_without_scratch_and_waits_with_counts(tmp_path):
+    """csrc/conv1x1_ring.hip runs ten waves per CU (eight consumers + two loaders = three on two of the SIMDs): 168 registers and no
+    scratch in every instantiation (the residual form sits AT 168; a second compute path or a resident bias tipped it into scratch during
+    round 5 - scratch traffic would sit in the loaders' counted vmcnt stream).  Its synchronisation rests on two things the source cannot
+    show: the loaders wait with COUNTED `s_waitcnt vmcnt(32)` in front of every barrier (a compiler-inserted `vmcnt(0)` there would
+    drain the prefetch), and the consumers' K-step has no vector-memory instruction between its barrier and its MFMAs."""
+    import proben_amd  # noqa: F401
+    from proben_amd import build
+    src = os.path.join(build.CSRC, "conv1x1_ring.hip")
+    out = tmp_path / "conv1x1_ring.s"
+    cmd = [build.hipcc(), "--offload-arch=" + build.ARCH, "-O3", "-std=c++17", "-x", "hip", "-S", "--cuda-device-only", src, "-o", str(out),
+           "-I", os.path.join(ROOT, "include"), "-I", build.CSRC] + build.EXTRA.get("conv1x1_ring.hip", build.EXTRA["default"])
+    subprocess.check_call(cmd)
+    text = out.read_text()
+    bodies = re.findall(r"\.amdhsa_kernel (\S*conv1x1_ring_kernel\S*)(.*?)\.end_amdhsa_kernel", text, flags=re.S)
+    assert len(bodies) == 4, "RELU x RES instantiations expected"
+    for name, body in bodies:
+        assert re.search(r"\.amdhsa_private_segment_fixed_size 0\b", body), name + ": scratch in use"
+        m = re.search(r"\.amdhsa_next_free_vgpr (\d+)", body)
+        assert m and int(m.group(1)) <= 168, (name, m and m.group(1))
+    # per kernel: every s_barrier of the loader loops is preceded (within a few instructions) by the counted wait, never by vmcnt(0)
+    for name, _ in bodies:
+        code = text[text.index(name + ":"):]
+        code = code[:code.index(".end_amdhsa_kernel")] if ".end_amdhsa_kernel" in code else code
+        lines = [l.strip() for l in code.splitlines() if l.strip() and not l.strip().startswith(";")]
+        counted = [i for i, l in enumerate(lines) if l == "s_waitcnt vmcnt(32)"]
+        assert len(counted) >= 2, name + ": the two loader loops wait with vmcnt(32)"
+        for i in counted:
+            window = lines[i + 1:i + 8]
+            assert any(l == "s_barrier" for l in window), (name, window)
+            assert not any(l.startswith("s_waitcnt vmcnt(0)") for l in window[:window.index("s_barrier")]), (name, window)
+        # the consumers' K-step: from its first MFMA to its last (16 MFMAs with the second half's fragment reads between them) there is no
+        # vector-memory instruction and no vmcnt wait - the matrix waves only read LDS and multiply
+        mf = [i for i, l in enumerate(lines) if l.startswith("v_mfma")]
+        assert len(mf) == 16, (name, len(mf))
+        block = lines[mf[0]:mf[-1] + 1]
+        assert not any(l.startswith(("buffer_", "global_", "flat_", "scratch_")) or "vmcnt" in l for l in block), name
+        assert sum(l.startswith("ds_read_b128") for l in block) == 8, name       # the pinned double-buffered schedule: sets 2 and 3 are read under MFMAs
