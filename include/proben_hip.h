@@ -105,6 +105,11 @@ int pe_proben_pack_detections(const float* const* det_boxes_host, const float* c
  *   residual_mode 0: none; 1: residual has the output's shape; 2: residual is [N,res_h,res_w,Cout]
  *             and is read at (oh/2, ow/2) (nearest-2x upsample).
  *   out_f32 != 0: fp32 output, only channels [0, cout_store) are written, row stride out_stride.
+ * Kernels behind it (all with the same fp32 summation order per output - K ascending, zero-initialised accumulators, then + bias,
+ * + residual, ReLU - so which one takes a launch never shows in a result, and the choice looks at channel counts / stride only, never at
+ * the batch): csrc/conv1x1_ring.hip (persistent loader / consumer kernel: 1x1 with a bias, fp16 output, Cout % 256 == 0, tensors < 2 GiB;
+ * residual-free from Cin 512 at stride 1 / 256 at stride 2, with a residual from Cin 128), csrc/conv_igemm2.hip (every other 1x1 and 3x3),
+ * csrc/conv_igemm.hip (the unfused stem).
  * ------------------------------------------------------------------------------------------- */
 int pe_conv2d_nhwc_f16(const void* input, const void* weight, const float* bias, const void* residual,
                        void* output, int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
