@@ -8,7 +8,8 @@
 // Kernel shape: the greedy clustering is inherently sequential in the pivot (<= N pivots per
 // image), so parallelism comes from (a) 64 lanes scoring the pivot against 64 candidates per
 // step with a ballot-compacted member list, (b) per-row logs / geometry precomputed in parallel,
-// (c) thousands of images in flight (one wave each, <= 32 waves per CU).  Per image the HBM
+// (c) the fusion formulas run AFTER the clustering, one lane per cluster (the clusters do not depend on them),
+// (d) thousands of images in flight (one wave each, <= 32 waves per CU).  Per image the HBM
 // traffic is N*(4+1+K+1)*8 + N*4 bytes in and M*(32+4+4+4) bytes out; everything else stays in LDS.
 #include "common.h"
 
@@ -41,6 +42,8 @@ __device__ __forceinline__ bool precedes(double sa, int ia, double sb, int ib) {
     return ia > ib;
 }
 
+// The rows' original boxes, 1 / variance and class ids are copied into LDS (by sorted position) next to the geometry: the fusion
+// touches no global memory (PE_SCORE_MAX excepted).
 __global__ __launch_bounds__(64) void proben_fuse_kernel(ProbenArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int img = blockIdx.x;
@@ -74,9 +77,15 @@ __global__ __launch_bounds__(64) void proben_fuse_kernel(ProbenArgs a) {
     double* gar = gy2 + R;
     double* gsc = gar + R;   // score
     double* glog = gsc + R;  // [L][R]
-    int* ord = reinterpret_cast<int*>(glog + (size_t)L * R);  // sorted position -> original row
-    unsigned short* members = reinterpret_cast<unsigned short*>(ord + R);
-    unsigned char* alive = reinterpret_cast<unsigned char*>(members + R);
+    double* gob = glog + (size_t)L * R;                       // [4][R] original coordinates
+    double* ginv = gob + 4 * (size_t)R;                       // 1 / variance (v-avg only)
+    int* ord = reinterpret_cast<int*>(ginv + R);              // sorted position -> original row
+    int* gcls = ord + R;                                      // class id
+    unsigned short* members = reinterpret_cast<unsigned short*>(gcls + R);   // all clusters' matches, back to back
+    unsigned short* cl_piv = members + R;      // per cluster: pivot position, first member, number of matches
+    unsigned short* cl_beg = cl_piv + R;
+    unsigned short* cl_cnt = cl_beg + R;
+    unsigned char* alive = reinterpret_cast<unsigned char*>(cl_cnt + R);
 
     // ---- 1. rank sort by score (scores staged through gar, indexed by ORIGINAL row) ----
     for (int r = lane; r < n; r += 64) gar[r] = a.scores[beg + r];
@@ -99,6 +108,9 @@ __global__ __launch_bounds__(64) void proben_fuse_kernel(ProbenArgs a) {
         gx1[p] = x1; gy1[p] = y1; gx2[p] = x2; gy2[p] = y2;
         gar[p] = (x2 - x1 + 1.0) * (y2 - y1 + 1.0);
         alive[p] = 1;
+        gob[p] = b[0]; gob[R + p] = b[1]; gob[2 * (size_t)R + p] = b[2]; gob[3 * (size_t)R + p] = b[3];
+        gcls[p] = a.classes[beg + r];
+        if (a.box_mode == PE_BOX_VAVG) ginv[p] = 1.0 / a.vars[beg + r];
         if (a.score_mode == PE_SCORE_PROBEN) {
             const double* pr = a.probs + (size_t)(beg + r) * K;
             double sum = 0.0;
@@ -116,8 +128,9 @@ __global__ __launch_bounds__(64) void proben_fuse_kernel(ProbenArgs a) {
     }
     __syncthreads();
 
-    // ---- 3. greedy pivots ----
-    int m_out = 0;
+    // ---- 3. greedy clustering: sequential in the pivot, 64 candidates per step; only the membership is recorded ----
+    // (the IoU tests use the rows' own geometry, never a fused box: the clusters do not depend on the fusion formulas)
+    int ncl = 0, cursor = 0;
     for (int pos = 0; pos < n; ++pos) {
         if (!alive[pos]) continue;  // wave-uniform (LDS broadcast)
         const double px1 = gx1[pos], py1 = gy1[pos], px2 = gx2[pos], py2 = gy2[pos], par = gar[pos];
@@ -134,54 +147,65 @@ __global__ __launch_bounds__(64) void proben_fuse_kernel(ProbenArgs a) {
                 if (!(ovr <= a.thr)) alive[q] = 0;  // matched or NaN: leaves the pool
             }
             const unsigned long long mask = __ballot(match);
-            if (match) members[cnt + __popcll(mask & pe::lanemask_lt())] = (unsigned short)q;
+            if (match) members[cursor + cnt + __popcll(mask & pe::lanemask_lt())] = (unsigned short)q;
             cnt += __popcll(mask);
         }
+        if (lane == 0) { cl_piv[ncl] = (unsigned short)pos; cl_beg[ncl] = (unsigned short)cursor; cl_cnt[ncl] = (unsigned short)cnt; }
+        cursor += cnt;
+        ++ncl;
         __syncthreads();
+    }
+    __syncthreads();
+    // ---- 4. fusion: one lane per cluster (cluster = matches in sorted order + the pivot LAST), output row = cluster index.
+    // The per-cluster arithmetic is the sequence the reference runs per pivot (sums over the members in cluster order, the
+    // normaliser summed over the columns in column order, first-maximum / first-NaN rules); it used to sit inside the pivot loop
+    // with 4 (+4) of the 64 lanes working and every latency of its dependent chains exposed ~100 times per image. ----
+    for (int k = lane; k < ncl; k += 64) {
+        const int pos = cl_piv[k], cnt = cl_cnt[k];
+        const unsigned short* mem = members + cl_beg[k];
+        const int m = cnt + 1;
         const int piv_row = ord[pos];
-        const int m = cnt + 1;  // cluster = matches (sorted order) + pivot LAST
+        auto at = [&](int t) { return t < cnt ? (int)mem[t] : pos; };
+        auto coord = [&](int c4, int p) { return gob[(size_t)c4 * R + p]; };
         double out_score = gsc[pos];
-        double out_class = (double)a.classes[beg + piv_row];
-        double out_coord = 0.0;  // lanes 8..11 hold x1,y1,x2,y2
-        const int c4 = lane - 8;
+        double out_class = (double)gcls[pos];
+        double out_coord[4];
         if (cnt == 0) {
-            if (c4 >= 0 && c4 < 4) out_coord = a.boxes[(size_t)(beg + piv_row) * 4 + c4];
+            for (int c4 = 0; c4 < 4; ++c4) out_coord[c4] = coord(c4, pos);
         } else {
             // ---------- score fusion ----------
             if (L > 0) {
-                double s = 0.0;
-                if (lane < L) {
+                auto column = [&](int j) {       // exp of the cluster's summed log-probability of column j
                     double acc = 0.0;
-                    const double* col = glog + (size_t)lane * R;
-                    for (int t = 0; t < m; ++t) acc += col[t < cnt ? members[t] : pos];
-                    s = exp(acc);
-                }
+                    const double* col = glog + (size_t)j * R;
+                    for (int t = 0; t < m; ++t) acc += col[at(t)];
+                    return exp(acc);
+                };
                 double tot = 0.0;
-                for (int j = 0; j < L; ++j) tot += __shfl(s, j);
-                const double norm = s / tot;
+                for (int j = 0; j < L; ++j) tot += column(j);
                 if (a.score_mode == PE_SCORE_PROBEN) {
                     // np.max / np.argmax over the K+1 entries INCLUDING background; NaN wins, first NaN index
-                    double best = __shfl(norm, 0);
+                    double best = column(0) / tot;
                     int bi = 0;
                     bool bnan = best != best;
                     for (int j = 1; j < L; ++j) {
-                        const double v = __shfl(norm, j);
+                        const double v = column(j) / tot;
                         if (!bnan && (v != v || v > best)) { best = v; bi = j; bnan = v != v; }
                     }
                     out_score = best;
                     out_class = (double)bi;
                 } else {
-                    out_score = __shfl(norm, 0);
+                    out_score = column(0) / tot;
                 }
             } else if (a.score_mode == PE_SCORE_AVG) {
                 double acc = 0.0;
-                for (int t = 0; t < m; ++t) acc += gsc[t < cnt ? members[t] : pos];
+                for (int t = 0; t < m; ++t) acc += gsc[at(t)];
                 out_score = acc / (double)m;
             } else {  // PE_SCORE_MAX: max over the whole [m,K] probability matrix
                 double best = -INFINITY;
                 bool bnan = false;
                 for (int t = 0; t < m; ++t) {
-                    const int r = ord[t < cnt ? members[t] : pos];
+                    const int r = ord[at(t)];
                     for (int j = 0; j < K; ++j) {
                         const double v = a.probs[(size_t)(beg + r) * K + j];
                         if (v != v) bnan = true;
@@ -190,49 +214,44 @@ __global__ __launch_bounds__(64) void proben_fuse_kernel(ProbenArgs a) {
                 }
                 out_score = bnan ? NAN : best;
             }
-            // ---------- box fusion (lanes 8..11, one coordinate each) ----------
-            if (c4 >= 0 && c4 < 4) {
-                if (a.box_mode == PE_BOX_VAVG || a.box_mode == PE_BOX_SAVG) {
-                    double wsum = 0.0;
-                    for (int t = 0; t < m; ++t) {
-                        const int p = t < cnt ? members[t] : pos;
-                        wsum += (a.box_mode == PE_BOX_VAVG) ? 1.0 / a.vars[beg + ord[p]] : gsc[p];
-                    }
+            // ---------- box fusion ----------
+            if (a.box_mode == PE_BOX_VAVG || a.box_mode == PE_BOX_SAVG) {
+                auto weight = [&](int p) { return (a.box_mode == PE_BOX_VAVG) ? ginv[p] : gsc[p]; };
+                double wsum = 0.0;
+                for (int t = 0; t < m; ++t) wsum += weight(at(t));
+                for (int c4 = 0; c4 < 4; ++c4) {
                     double acc = 0.0;
                     for (int t = 0; t < m; ++t) {
-                        const int p = t < cnt ? members[t] : pos;
-                        const int r = ord[p];
-                        const double w = (a.box_mode == PE_BOX_VAVG) ? 1.0 / a.vars[beg + r] : gsc[p];
-                        acc += a.boxes[(size_t)(beg + r) * 4 + c4] * (w / wsum);
+                        const int p = at(t);
+                        acc += coord(c4, p) * (weight(p) / wsum);
                     }
-                    out_coord = acc;
-                } else if (a.box_mode == PE_BOX_AVG) {
-                    double acc = 0.0;
-                    for (int t = 0; t < m; ++t) acc += a.boxes[(size_t)(beg + ord[t < cnt ? members[t] : pos]) * 4 + c4];
-                    out_coord = acc / (double)m;
-                } else {  // argmax: box of the first maximal score in cluster order
-                    int bp = cnt > 0 ? members[0] : pos;
-                    double best = gsc[bp];
-                    bool bnan = best != best;
-                    for (int t = 1; t < m; ++t) {
-                        const int p = t < cnt ? members[t] : pos;
-                        const double v = gsc[p];
-                        if (!bnan && (v != v || v > best)) { best = v; bp = p; bnan = v != v; }
-                    }
-                    out_coord = a.boxes[(size_t)(beg + ord[bp]) * 4 + c4];
+                    out_coord[c4] = acc;
                 }
+            } else if (a.box_mode == PE_BOX_AVG) {
+                for (int c4 = 0; c4 < 4; ++c4) {
+                    double acc = 0.0;
+                    for (int t = 0; t < m; ++t) acc += coord(c4, at(t));
+                    out_coord[c4] = acc / (double)m;
+                }
+            } else {  // argmax: box of the first maximal score in cluster order
+                int bp = at(0);
+                double best = gsc[bp];
+                bool bnan = best != best;
+                for (int t = 1; t < m; ++t) {
+                    const int p = at(t);
+                    const double v = gsc[p];
+                    if (!bnan && (v != v || v > best)) { best = v; bp = p; bnan = v != v; }
+                }
+                for (int c4 = 0; c4 < 4; ++c4) out_coord[c4] = coord(c4, bp);
             }
         }
-        const size_t o = (size_t)beg + m_out;
-        if (lane == 0) {
-            a.out_scores[o] = (float)out_score;
-            a.out_classes[o] = (float)out_class;
-            a.out_keep[o] = piv_row;
-        }
-        if (c4 >= 0 && c4 < 4) a.out_boxes[o * 4 + c4] = out_coord;
-        ++m_out;
+        const size_t o = (size_t)beg + k;
+        a.out_scores[o] = (float)out_score;
+        a.out_classes[o] = (float)out_class;
+        a.out_keep[o] = piv_row;
+        for (int c4 = 0; c4 < 4; ++c4) a.out_boxes[o * 4 + c4] = out_coord[c4];
     }
-    if (lane == 0) a.out_counts[img] = m_out;
+    if (lane == 0) a.out_counts[img] = ncl;
 }
 
 struct PackArgs {
@@ -344,7 +363,7 @@ extern "C" int pe_proben_fuse_batch(const double* boxes, const double* scores, c
                  "pe_proben_fuse_batch: max_rows_per_image %d not in [1,2048]", max_rows_per_image);
     const int R = (max_rows_per_image + 1) & ~1;  // keep the int/short/byte carves 8-byte aligned
     const int L = score_mode == PE_SCORE_PROBEN ? num_classes + 1 : (score_mode == PE_SCORE_PROBEN_BINARY ? 2 : 0);
-    const size_t lds = (size_t)R * (8 * (6 + L) + 4 + 2 + 1) + 16;
+    const size_t lds = (size_t)R * (8 * (6 + L + 5) + 4 + 4 + 4 * 2 + 1) + 16;
     if (lds > 160 * 1024) {
         pe::set_error("pe_proben_fuse_batch: %zu bytes of LDS needed (> 160 KiB); lower max_rows_per_image", lds);
         return PE_ERR_UNSUPPORTED;
@@ -353,8 +372,7 @@ extern "C" int pe_proben_fuse_batch(const double* boxes, const double* scores, c
                  score_mode, box_mode, iou_thresh, frame_w, frame_h,
                  out_boxes, out_scores, out_classes, out_keep, out_counts};
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(proben_fuse_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(proben_fuse_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {
             pe::set_error("pe_proben_fuse_batch: cannot raise dynamic LDS to %zu: %s", lds, hipGetErrorString(e));
             return PE_ERR_HIP;

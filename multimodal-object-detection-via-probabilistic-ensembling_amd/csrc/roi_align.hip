@@ -15,7 +15,10 @@
 // Output layout: [R, ph, pw, C] (the box head's fc1 weight is permuted to match at load time).
 #include <hip/hip_fp16.h>
 
+#include <atomic>
+
 #include "common.h"
+#include "test_hooks.h"
 
 namespace {
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -95,11 +98,15 @@ __device__ void sep_build_axis(SepTables& t, int axis, int bin, float start, flo
     int lo_min = 0x7fffffff, hi_max = -1;
     for (int pass = 0; pass < 2; ++pass) {
         if (pass == 1) {
-            if (hi_max < 0) { t.n[axis][bin] = 0; t.first[axis][bin] = 0; return; }
+            if (hi_max < 0) {       // no valid sample on this axis: an empty window (its weights still zeroed - a neighbour bin's window may be walked)
+                t.n[axis][bin] = 0; t.first[axis][bin] = 0;
+                for (int i = 0; i < SEP_MAXN; ++i) t.w[axis][bin][i] = 0.f;
+                return;
+            }
             const int n = hi_max - lo_min + 1;
             if (n > SEP_MAXN) { t.fallback = 1; t.n[axis][bin] = 0; return; }
             t.n[axis][bin] = n; t.first[axis][bin] = lo_min;
-            for (int i = 0; i < n; ++i) t.w[axis][bin][i] = 0.f;
+            for (int i = 0; i < SEP_MAXN; ++i) t.w[axis][bin][i] = 0.f;   // the whole row: the wave-uniform loop below pads with zero weights
         }
         for (int i = 0; i < grid; ++i) {
             float y = start + (float)(i + .5f) * bin_size / (float)grid;
@@ -118,7 +125,40 @@ __device__ void sep_build_axis(SepTables& t, int axis, int bin, float start, flo
     }
 }
 
-template <typename T, bool SEP>
+// acc += (float)half * w in ONE instruction (v_fma_mix_f32: the fp16 -> fp32 conversion is exact, the FMA rounds once - the bits of
+// v_cvt_f32_f16 + v_fma_f32, at 8 instead of 12 issue slots per 16-byte load; the compiler prefers 8 converts + 4 packed FMAs)
+__device__ inline float fma_mix_lo(unsigned hp, float w, float acc) {
+    float d;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(hp), "v"(w), "v"(acc));
+    return d;
+}
+__device__ inline float fma_mix_hi(unsigned hp, float w, float acc) {
+    float d;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(hp), "v"(w), "v"(acc));
+    return d;
+}
+typedef unsigned uint4v __attribute__((ext_vector_type(4)));
+__device__ inline void fma_mix8(const uint4v& h, float w, float* acc) {
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        acc[2 * d] = fma_mix_lo(h[d], w, acc[2 * d]);
+        acc[2 * d + 1] = fma_mix_hi(h[d], w, acc[2 * d + 1]);
+    }
+}
+std::atomic<int> g_roi_fast{1};   // test hook: 0 = the per-lane form for every launch (A/B and the bit-identity test)
+
+// FAST (fp16, C == 256, pooled <= 8 x 8, one pooled row per pass): the wave-uniform form of the separable loop.  A wave owns two
+// horizontally adjacent bins (32 lanes x 8 channels each) of one pooled row: the row window (first, n, weights) is the same for both,
+// and the column loop runs over the WIDER of the two windows with zero weights padding the narrower one - so the pixel walk
+// (row, column, byte offset, loop ends) is scalar arithmetic on the SALU, the lanes only differ by a constant voffset, and the
+// loads are buffer loads bounded to the image's level (a padded column past the level's end reads zeros instead of faulting).
+// Per pixel and wave: 1 load, 2 LDS reads, 1 multiply, 8 v_fma_mix - ~12 vector issue slots where the per-lane form needs ~29
+// (that form is VALU-issue bound: 488 M VALU instructions per launch of 32 000 ROIs = 98 % of the SIMD cycles of its 0.90 ms; this
+// one 199 M = 65 % of 0.57 ms, profiles/r05_roi_fast_ab.txt; 4 loads in flight per wave: 3, 6, 8 and 8 waves per SIMD are all
+// within 5 %).  A bin's own pixels are accumulated in the
+// same row-major order with the same weights; the padding adds w = 0 terms, which leave an accumulator that started at +0 as it is
+// -> the bits of the per-lane form (tests/test_ops_gpu.py::test_roi_align_fast_form_is_bit_identical).
+template <typename T, bool SEP, bool FAST>
 __global__ __launch_bounds__(256) void roi_align_kernel(RoiArgs a) {
     constexpr int V = Vec<T>::N;
     int r = blockIdx.x;
@@ -177,6 +217,79 @@ __global__ __launch_bounds__(256) void roi_align_kernel(RoiArgs a) {
             else if (t < a.ph + a.pw) sep_build_axis(tabs, 1, t - a.ph, start_w + (t - a.ph) * bin_w, bin_w, grid_w, W);
         }
         __syncthreads();
+    }
+    if constexpr (FAST) {
+        if (live && !tabs.fallback) {
+            const int pw = (int)threadIdx.x >> 5, cv = (int)threadIdx.x & 31;
+            const int pwa = __builtin_amdgcn_readfirstlane(pw), pwb = min(pwa + 1, a.pw - 1);
+            const int nxm = __builtin_amdgcn_readfirstlane(max(tabs.n[1][pwa], tabs.n[1][pwb]));
+            const float* wxr = tabs.w[1][pw];
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(feat), 0, H * W * a.C * 2, 0x00020000);
+            const unsigned voff = (unsigned)(tabs.first[1][pw] * a.C + cv * 8) * 2u;
+            const unsigned step_c = (unsigned)a.C * 2u, step_r = (unsigned)(W - nxm + 1) * a.C * 2u;
+            // x / count, correctly rounded, in 3 instead of ~10 instructions: with y = RN(1 / count), q = RN(x * y) is refined once
+            // through the exact residual (Markstein).  Checked exhaustively against IEEE division over all 2^23 significands for every
+            // count = g1 * g2, g <= 22 (the tables hold at most 20 pixels per bin, i.e. a sampling grid below 20); beyond: divide.
+            const bool short_div = grid_h <= 22 && grid_w <= 22;
+            const float rcp = 1.f / count;
+            constexpr int MLP = ROI_MLP;
+            for (int ph = 0; ph < a.ph; ++ph) {
+                const int ny = __builtin_amdgcn_readfirstlane(tabs.n[0][ph]);
+                const unsigned row0 = (unsigned)__builtin_amdgcn_readfirstlane(tabs.first[0][ph]) * (unsigned)W * step_c;
+                const float* wyr = tabs.w[0][ph];
+                const int npx = ny * nxm;
+                float acc[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+                unsigned soff = row0;
+                int rr = 0, c = 0, i = 0;
+                for (; i + MLP <= npx; i += MLP) {
+                    uint4v h[MLP];
+                    float w[MLP];
+#pragma unroll
+                    for (int u = 0; u < MLP; ++u) {
+                        w[u] = wyr[rr] * wxr[c];
+                        h[u] = __builtin_bit_cast(uint4v, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
+                        const bool wrap = c + 1 == nxm;
+                        soff += wrap ? step_r : step_c;
+                        c = wrap ? 0 : c + 1;
+                        rr += wrap ? 1 : 0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < MLP; ++u) fma_mix8(h[u], w[u], acc);
+                }
+                if (i < npx) {      // the pass's last, partial group: its loads in flight together, none issued past the end (wave-uniform branches)
+                    uint4v h[MLP - 1];
+                    float w[MLP - 1];
+                    const int rem = npx - i;
+#pragma unroll
+                    for (int u = 0; u < MLP - 1; ++u)
+                        if (u < rem) {
+                            w[u] = wyr[rr] * wxr[c];
+                            h[u] = __builtin_bit_cast(uint4v, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
+                            const bool wrap = c + 1 == nxm;
+                            soff += wrap ? step_r : step_c;
+                            c = wrap ? 0 : c + 1;
+                            rr += wrap ? 1 : 0;
+                        }
+#pragma unroll
+                    for (int u = 0; u < MLP - 1; ++u)
+                        if (u < rem) fma_mix8(h[u], w[u], acc);
+                }
+                if (short_div) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float q = acc[e] * rcp;
+                        acc[e] = __builtin_fmaf(__builtin_fmaf(-count, q, acc[e]), rcp, q);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[e] /= count;
+                }
+                Vec<T>::store(out + ((size_t)ph * a.pw + pw) * a.C + cv * 8, acc);
+            }
+            return;
+        }
     }
     for (int it = threadIdx.x; it < items; it += blockDim.x) {
         const int cv = it % cvec, bin = it / cvec;
@@ -245,6 +358,7 @@ __global__ __launch_bounds__(256) void roi_align_kernel(RoiArgs a) {
         Vec<T>::store(out + (size_t)bin * a.C + cv * V, acc);
     }
 }
+
 // ---- processing order ("(level, y, x) ROI ordering / XCD-affine mapping") ---------------------------------------
 // One workgroup per image sorts its proposals by (dead slot, FPN level, Morton code of the box centre in 32-px cells): bitonic
 // sort of 2048 packed 32-bit keys in LDS, the ROI's index in the low 11 bits (keys are unique -> the order is deterministic).
@@ -452,12 +566,21 @@ static int roi_align_forward(const void* const* feats_host, const int32_t* feat_
         // 6 full + 1 one-eighth-full pass of 256)
         const int row_threads = (C / 8) * pooled_w;
         const int threads = row_threads <= 256 ? row_threads : 256;
-        hipLaunchKernelGGL((roi_align_kernel<_Float16, true>), dim3(grid), dim3(threads), 0, (hipStream_t)stream, a);
+        const int fast = g_roi_fast.load(std::memory_order_relaxed);
+        if (C == 256 && pooled_h <= SEP_MAXB && pooled_w <= SEP_MAXB && fast) {
+            hipLaunchKernelGGL((roi_align_kernel<_Float16, true, true>), dim3(grid), dim3(threads), 0, (hipStream_t)stream, a);
+        } else
+            hipLaunchKernelGGL((roi_align_kernel<_Float16, true, false>), dim3(grid), dim3(threads), 0, (hipStream_t)stream, a);
     }
     else
-        hipLaunchKernelGGL((roi_align_kernel<float, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL((roi_align_kernel<float, false, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
     PE_CHECK_LAUNCH("pe_roi_align_nhwc");
     return PE_OK;
+}
+
+extern "C" int pe_test_set_roi_fast(int on) {
+    g_roi_fast.store(on ? 1 : 0, std::memory_order_relaxed);
+    return 0;
 }
 
 extern "C" int pe_roi_align_nhwc(const void* const* feats_host, const int32_t* feat_hw_host, const float* scales_host,

@@ -29,6 +29,8 @@ int pe_test_set_wd9_wgs(int pure, int tail);
 int pe_test_set_ring_wgs(int wgs);
 /* ablation builds of the ring kernel (csrc/conv1x1_ring.hip RingArgs::abl; non-zero = wrong results, timing only) */
 int pe_test_set_ring_ablation(int bits);
+/* ROIAlign (fp16, C == 256): 1 (default) = the wave-uniform form, 0 = the per-lane form for every launch (same bits; A/B and the identity test) */
+int pe_test_set_roi_fast(int on);
 #ifdef __cplusplus
 }
 #endif

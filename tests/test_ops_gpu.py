@@ -771,6 +771,44 @@ def test_roi_align_sorted_order_moves_no_result(L, N, P):
         assert float(a.view(N, P, -1)[1, counts[1]:].abs().sum()) == 0
 
 
+@pytest.mark.parametrize("pooled,ratio,aligned,tiny", [((7, 7), 0, True, False), ((7, 7), 0, True, True), ((8, 8), 0, False, False), ((3, 5), 2, True, False), ((7, 7), 3, False, False)])
+def test_roi_align_fast_form_is_bit_identical(L, pooled, ratio, aligned, tiny):
+    """The wave-uniform form (fp16, C = 256: two bins per wave walk the wider of their two windows, scalar pixel walk, v_fma_mix,
+    three-instruction exact division) against the per-lane form it replaces in the detector: the same bits.  Boxes cover every
+    level, sub-pixel and whole-image sizes, boxes partly and wholly outside the image (empty windows next to live ones), the last
+    image's bottom-right corner (padded columns run past the level's end: bounded buffer loads) and - single level, stride 4 - bins
+    above the table size (tap-form fallback inside the fast kernel); `tiny` scales the features into fp16 subnormals."""
+    from proben_amd import _lib
+    H = _lib.test_hooks()
+    N, P = 3, 700
+    g = torch.Generator().manual_seed(pooled[0] * 131 + ratio * 17 + int(aligned) + 2 * int(tiny))
+    feats = [(torch.randn(N, 200 >> l, 256 >> l, 256, generator=g) * (2e-6 if tiny else 1.0)).half().cuda() for l in range(4)]
+    feats[2][:, 5:9, 3:11] = 0
+    ctr = torch.rand(N, P, 2, generator=g) * torch.tensor([1100.0, 860.0]) - torch.tensor([40.0, 30.0])
+    wh = torch.exp(torch.rand(N, P, 2, generator=g) * 7.0 - 0.5)              # 0.6 .. 660 px, independent sides: elongated boxes too
+    boxes = torch.cat([ctr - wh / 2, ctr + wh / 2], dim=2)
+    boxes[:, 0] = torch.tensor([-50.0, -40.0, 1100.0, 900.0])                # beyond the image on every side
+    boxes[:, 1] = torch.tensor([1500.0, 900.0, 1600.0, 1000.0])              # wholly outside: empty windows
+    boxes[:, 2] = torch.tensor([1000.0, 780.0, 1024.0, 800.0])               # bottom-right corner
+    boxes[:, 3] = torch.tensor([1010.0, 100.0, 1300.0, 300.0])               # left columns live, right columns outside
+    boxes[:, 4] = torch.tensor([100.0, 100.0, 100.0, 100.0])                 # empty box
+    boxes = boxes.cuda()
+    counts = torch.tensor([P, P - 9, 5], dtype=torch.int32).cuda()
+    cases = [dict(feats=feats, scales=[1 / 4, 1 / 8, 1 / 16, 1 / 32]), dict(feats=feats[:1], scales=[1 / 4]), dict(feats=feats[3:], scales=[1 / 32])]
+    try:
+        for case in cases:
+            kw = dict(scales=case["scales"], pooled=pooled, sampling_ratio=ratio, aligned=aligned, counts=counts, per_image=P)
+            outs = []
+            for fast in (1, 0):
+                H.pe_test_set_roi_fast(fast)
+                outs.append([L.roi_align_nhwc(case["feats"], boxes, sort=s, **kw) for s in (False, True)])
+            assert torch.equal(outs[0][0].view(torch.int16), outs[1][0].view(torch.int16))
+            assert torch.equal(outs[0][1].view(torch.int16), outs[1][1].view(torch.int16))
+            assert float(outs[0][0].float().abs().sum()) > 0
+    finally:
+        H.pe_test_set_roi_fast(1)
+
+
 def test_roi_align_backward_matches_oracle_and_autograd(L):
     """Training half: the backward kernel == the oracle's restatement of ROIAlign_cpu.cpp:221-394 (atomics:
     tolerance, not bits), rows beyond counts contribute nothing, and `layers.ROIAlign` is differentiable end to end."""

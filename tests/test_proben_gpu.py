@@ -82,6 +82,28 @@ def test_hip_matches_oracle_batched(sm, bm, kdet):
         np.testing.assert_allclose(ob[sl], eb, rtol=1e-9, atol=1e-9, equal_nan=True)
 
 
+@pytest.mark.parametrize("sm,bm", [("probEn", "v-avg"), ("avg", "s-avg"), ("max", "avg"), ("probEn", "argmax")])
+def test_image_bound_moves_no_bit(sm, bm):
+    """The per-image row bound only sizes the LDS carve (csrc/proben.hip keeps every row's geometry, logs, box, 1 / variance and
+    class id there): the detectors' bound (the longest image here) and 1100 rows (147 KB, above the 64 KiB default) give the same
+    outputs; a bound that does not fit 160 KiB is refused, not truncated."""
+    from proben_amd import _lib, fusion as F
+    per_image = synth_batch(40, seed=23, kdet=3)
+    b, s, p, v, c, offs = F.pack_infos(per_image)
+    tight = F.fuse_batch(b, s, p, v, c, offs, sm, bm)
+    wide = F.fuse_batch(b, s, p, v, c, offs, sm, bm, max_rows=1100)
+    assert torch.equal(tight["counts"], wide["counts"]) and int(tight["counts"].sum()) > 0
+    offs_h, cnt = offs.cpu().numpy(), tight["counts"].cpu().numpy()
+    for i in range(len(per_image)):
+        sl = slice(offs_h[i], offs_h[i] + cnt[i])
+        assert torch.equal(tight["keep"][sl], wide["keep"][sl])
+        assert torch.equal(tight["boxes"][sl].view(torch.int64), wide["boxes"][sl].view(torch.int64))
+        assert torch.equal(tight["scores"][sl].view(torch.int32), wide["scores"][sl].view(torch.int32))
+        assert torch.equal(tight["classes"][sl], wide["classes"][sl])
+    with pytest.raises(_lib.HipLibraryError, match="LDS"):
+        F.fuse_batch(b, s, p, v, c, offs, sm, bm, max_rows=2000)
+
+
 def test_binary_mode_k1():
     """K = 1 (KAIST, config 5): pe score mode PROBEN_BINARY == demo_probEn.py:24-30."""
     from oracle import proben as O
