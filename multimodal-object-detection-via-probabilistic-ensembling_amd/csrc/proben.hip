@@ -42,35 +42,55 @@ __device__ __forceinline__ bool precedes(double sa, int ia, double sb, int ib) {
     return ia > ib;
 }
 
-// The rows' original boxes, 1 / variance and class ids are copied into LDS (by sorted position) next to the geometry: the fusion
-// touches no global memory (PE_SCORE_MAX excepted).
-__global__ __launch_bounds__(64) void proben_fuse_kernel(ProbenArgs a) {
+// One 1024-thread workgroup per image (one per CU; a step has 32 of them).  The rows' original boxes, 1 / variance and class ids
+// are copied into LDS (by sorted position) next to the geometry: nothing after the second phase touches global memory (PE_SCORE_MAX
+// excepted).  Phases: 1 rank sort (a thread per row), 2 geometry + logs (a thread per row), 3 clustering, 4 fusion (a thread per
+// cluster).  Clustering, BITS form: (a) all 16 waves fill two bit matrices over the sorted rows, match[p][q] = IoU > thr and
+// kill[p][q] = !(IoU <= thr) for q > p (a ballot per 64 candidates - the IoU tests use the rows' own geometry, never a fused box,
+// so they do not depend on the order the pivots are visited in); (b) wave 0 walks the rows in order with the alive set in registers
+// (lane w = rows 64w .. 64w+63): a live row becomes a pivot, its cluster = match row & alive, alive &= ~kill row - four rows'
+// matrix lines are fetched per LDS round trip.  The sequential form (below, when the matrices do not fit the LDS) computes the
+// IoUs inside the walk: ~1 500 cycles per row against ~100; with the rank sort on one wave that was 0.26 ms per step at the END
+// of the step, where nothing overlaps it (profiles/r05_proben_phases.txt).
+constexpr int kFuseThreads = 1024;
+
+__device__ __forceinline__ unsigned long long readlane64(unsigned long long v, int l) {
+    const unsigned lo = __builtin_amdgcn_readlane((unsigned)v, l), hi = __builtin_amdgcn_readlane((unsigned)(v >> 32), l);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+template <bool BITS>
+__global__ __launch_bounds__(kFuseThreads) void proben_fuse_kernel(ProbenArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ int ncl_s;
     const int img = blockIdx.x;
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int beg = a.offsets[img];
     const int n = a.row_counts ? a.row_counts[img] : a.offsets[img + 1] - beg;
     if (n > a.max_rows || n < 0) {
-        if (lane == 0) a.out_counts[img] = -1;
+        if (tid == 0) a.out_counts[img] = -1;
         return;
     }
     if (a.passthrough && a.passthrough[img]) {  // exactly one detector fired: rows pass through unchanged
-        for (int r = lane; r < n; r += 64) {
+        for (int r = tid; r < n; r += kFuseThreads) {
             const size_t o = (size_t)beg + r;
             for (int e = 0; e < 4; ++e) a.out_boxes[o * 4 + e] = a.boxes[o * 4 + e];
             a.out_scores[o] = (float)a.scores[o];
             a.out_classes[o] = (float)a.classes[o];
             a.out_keep[o] = r;
         }
-        if (lane == 0) a.out_counts[img] = n;
+        if (tid == 0) a.out_counts[img] = n;
         return;
     }
     const int R = a.max_rows;
     const int K = a.K;
+    const int W = (R + 63) >> 6;   // 64-row words per matrix line
     // columns of log-probabilities kept per row (0 when the score mode does not need them)
     const int L = (a.score_mode == PE_SCORE_PROBEN) ? K + 1 : (a.score_mode == PE_SCORE_PROBEN_BINARY ? 2 : 0);
     // ---- LDS carve (all arrays indexed by SORTED position unless noted) ----
-    double* gx1 = reinterpret_cast<double*>(smem);
+    unsigned long long* mbits = reinterpret_cast<unsigned long long*>(smem);      // BITS: match [R][W], then the clusters' member bits
+    unsigned long long* kbits = mbits + (BITS ? (size_t)R * W : 0);               // BITS: kill [R][W]
+    double* gx1 = reinterpret_cast<double*>(kbits + (BITS ? (size_t)R * W : 0));
     double* gy1 = gx1 + R;
     double* gx2 = gy1 + R;
     double* gy2 = gx2 + R;
@@ -85,21 +105,22 @@ __global__ __launch_bounds__(64) void proben_fuse_kernel(ProbenArgs a) {
     unsigned short* cl_piv = members + R;      // per cluster: pivot position, first member, number of matches
     unsigned short* cl_beg = cl_piv + R;
     unsigned short* cl_cnt = cl_beg + R;
-    unsigned char* alive = reinterpret_cast<unsigned char*>(cl_cnt + R);
+    unsigned char* alive = reinterpret_cast<unsigned char*>(cl_cnt + R);       // sequential form only
 
     // ---- 1. rank sort by score (scores staged through gar, indexed by ORIGINAL row) ----
-    for (int r = lane; r < n; r += 64) gar[r] = a.scores[beg + r];
+    for (int r = tid; r < n; r += kFuseThreads) gar[r] = a.scores[beg + r];
     __syncthreads();
-    for (int r = lane; r < n; r += 64) {
+    for (int r = tid; r < n; r += kFuseThreads) {
         const double s = gar[r];
         int rank = 0;
+#pragma unroll 8
         for (int q = 0; q < n; ++q) rank += precedes(gar[q], q, s, r) ? 1 : 0;
         ord[rank] = r;
         gsc[rank] = s;
     }
     __syncthreads();
     // ---- 2. per-row geometry (class-band shifted, legacy "+1" area) and log-probabilities ----
-    for (int p = lane; p < n; p += 64) {
+    for (int p = tid; p < n; p += kFuseThreads) {
         const int r = ord[p];
         const double c = (double)a.classes[beg + r];
         const double* b = a.boxes + (size_t)(beg + r) * 4;
@@ -107,7 +128,7 @@ __global__ __launch_bounds__(64) void proben_fuse_kernel(ProbenArgs a) {
         const double x2 = b[2] + c * a.fw, y2 = b[3] + c * a.fh;
         gx1[p] = x1; gy1[p] = y1; gx2[p] = x2; gy2[p] = y2;
         gar[p] = (x2 - x1 + 1.0) * (y2 - y1 + 1.0);
-        alive[p] = 1;
+        if (!BITS) alive[p] = 1;
         gob[p] = b[0]; gob[R + p] = b[1]; gob[2 * (size_t)R + p] = b[2]; gob[3 * (size_t)R + p] = b[3];
         gcls[p] = a.classes[beg + r];
         if (a.box_mode == PE_BOX_VAVG) ginv[p] = 1.0 / a.vars[beg + r];
@@ -128,41 +149,105 @@ __global__ __launch_bounds__(64) void proben_fuse_kernel(ProbenArgs a) {
     }
     __syncthreads();
 
-    // ---- 3. greedy clustering: sequential in the pivot, 64 candidates per step; only the membership is recorded ----
-    // (the IoU tests use the rows' own geometry, never a fused box: the clusters do not depend on the fusion formulas)
-    int ncl = 0, cursor = 0;
-    for (int pos = 0; pos < n; ++pos) {
-        if (!alive[pos]) continue;  // wave-uniform (LDS broadcast)
-        const double px1 = gx1[pos], py1 = gy1[pos], px2 = gx2[pos], py2 = gy2[pos], par = gar[pos];
-        int cnt = 0;
-        for (int base = pos + 1; base < n; base += 64) {
-            const int q = base + lane;
-            bool match = false;
-            if (q < n && alive[q]) {
-                const double w = fmax(0.0, fmin(px2, gx2[q]) - fmax(px1, gx1[q]) + 1.0);
-                const double h = fmax(0.0, fmin(py2, gy2[q]) - fmax(py1, gy1[q]) + 1.0);
-                const double inter = w * h;
-                const double ovr = inter / (par + gar[q] - inter);
-                match = ovr > a.thr;
-                if (!(ovr <= a.thr)) alive[q] = 0;  // matched or NaN: leaves the pool
+    // ---- 3. greedy clustering: only the membership is recorded ----
+    if (BITS) {
+        // (a) the pair tests: one (row, 64 candidates) item per wave step
+        const int Wn = (n + 63) >> 6;
+        for (int item = wave; item < n * Wn; item += kFuseThreads / 64) {
+            const int p = item / Wn, c = item - p * Wn;
+            unsigned long long m = 0, kl = 0;
+            if (c >= (p >> 6)) {
+                const int q = c * 64 + lane;
+                bool match = false, kill = false;
+                if (q > p && q < n) {
+                    const double px1 = gx1[p], py1 = gy1[p], px2 = gx2[p], py2 = gy2[p], par = gar[p];
+                    const double w = fmax(0.0, fmin(px2, gx2[q]) - fmax(px1, gx1[q]) + 1.0);
+                    const double h = fmax(0.0, fmin(py2, gy2[q]) - fmax(py1, gy1[q]) + 1.0);
+                    const double inter = w * h;
+                    const double ovr = inter / (par + gar[q] - inter);
+                    match = ovr > a.thr;
+                    kill = !(ovr <= a.thr);      // matched or NaN: leaves the pool
+                }
+                m = __ballot(match);
+                kl = __ballot(kill);
             }
-            const unsigned long long mask = __ballot(match);
-            if (match) members[cursor + cnt + __popcll(mask & pe::lanemask_lt())] = (unsigned short)q;
-            cnt += __popcll(mask);
+            if (lane == 0) { mbits[(size_t)p * W + c] = m; kbits[(size_t)p * W + c] = kl; }
         }
-        if (lane == 0) { cl_piv[ncl] = (unsigned short)pos; cl_beg[ncl] = (unsigned short)cursor; cl_cnt[ncl] = (unsigned short)cnt; }
-        cursor += cnt;
-        ++ncl;
         __syncthreads();
+        // (b) the walk
+        if (wave == 0) {
+            unsigned long long live = 0;       // lane w: rows 64w .. 64w + 63
+            if (lane < Wn) live = (n - lane * 64 >= 64) ? ~0ull : ((1ull << (n - lane * 64)) - 1ull);
+            int ncl = 0, cursor = 0;
+            for (int p0 = 0; p0 < n; p0 += 4) {
+                unsigned long long mrow[4], krow[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const bool ok = p0 + u < n && lane < Wn;
+                    mrow[u] = ok ? mbits[(size_t)(p0 + u) * W + lane] : 0ull;
+                    krow[u] = ok ? kbits[(size_t)(p0 + u) * W + lane] : 0ull;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int p = p0 + u;
+                    if (p >= n) break;
+                    if (!((readlane64(live, p >> 6) >> (p & 63)) & 1ull)) continue;   // wave-uniform
+                    const unsigned long long mem = mrow[u] & live;
+                    live &= ~krow[u];
+                    int cnt = 0;
+                    for (int w = 0; w < Wn; ++w) cnt += __popcll(readlane64(mem, w));
+                    if (lane < Wn) mbits[(size_t)p * W + lane] = mem;       // the line now holds the cluster's members
+                    if (lane == 0) { cl_piv[ncl] = (unsigned short)p; cl_beg[ncl] = (unsigned short)cursor; cl_cnt[ncl] = (unsigned short)cnt; }
+                    cursor += cnt;
+                    ++ncl;
+                }
+            }
+            if (lane == 0) ncl_s = ncl;
+        }
+    } else if (wave == 0) {
+        // sequential in the pivot, 64 candidates per step, IoUs computed on the way
+        int ncl = 0, cursor = 0;
+        for (int pos = 0; pos < n; ++pos) {
+            if (!alive[pos]) continue;  // wave-uniform (LDS broadcast)
+            const double px1 = gx1[pos], py1 = gy1[pos], px2 = gx2[pos], py2 = gy2[pos], par = gar[pos];
+            int cnt = 0;
+            for (int base = pos + 1; base < n; base += 64) {
+                const int q = base + lane;
+                bool match = false;
+                if (q < n && alive[q]) {
+                    const double w = fmax(0.0, fmin(px2, gx2[q]) - fmax(px1, gx1[q]) + 1.0);
+                    const double h = fmax(0.0, fmin(py2, gy2[q]) - fmax(py1, gy1[q]) + 1.0);
+                    const double inter = w * h;
+                    const double ovr = inter / (par + gar[q] - inter);
+                    match = ovr > a.thr;
+                    if (!(ovr <= a.thr)) alive[q] = 0;  // matched or NaN: leaves the pool
+                }
+                const unsigned long long mask = __ballot(match);
+                if (match) members[cursor + cnt + __popcll(mask & pe::lanemask_lt())] = (unsigned short)q;
+                cnt += __popcll(mask);
+            }
+            if (lane == 0) { cl_piv[ncl] = (unsigned short)pos; cl_beg[ncl] = (unsigned short)cursor; cl_cnt[ncl] = (unsigned short)cnt; }
+            cursor += cnt;
+            ++ncl;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // alive[] is re-read by other lanes of this wave
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (lane == 0) ncl_s = ncl;
     }
     __syncthreads();
+    const int ncl = ncl_s;
     // ---- 4. fusion: one lane per cluster (cluster = matches in sorted order + the pivot LAST), output row = cluster index.
     // The per-cluster arithmetic is the sequence the reference runs per pivot (sums over the members in cluster order, the
     // normaliser summed over the columns in column order, first-maximum / first-NaN rules); it used to sit inside the pivot loop
     // with 4 (+4) of the 64 lanes working and every latency of its dependent chains exposed ~100 times per image. ----
-    for (int k = lane; k < ncl; k += 64) {
+    for (int k = tid; k < ncl; k += kFuseThreads) {
         const int pos = cl_piv[k], cnt = cl_cnt[k];
-        const unsigned short* mem = members + cl_beg[k];
+        unsigned short* mem = members + cl_beg[k];
+        if (BITS) {     // the member bits in ascending (= sorted) order; this thread's own stretch of the list
+            int i = 0;
+            for (int w = pos >> 6; w < ((n + 63) >> 6); ++w)
+                for (unsigned long long bits = mbits[(size_t)pos * W + w]; bits; bits &= bits - 1ull) mem[i++] = (unsigned short)(w * 64 + __builtin_ctzll(bits));
+        }
         const int m = cnt + 1;
         const int piv_row = ord[pos];
         auto at = [&](int t) { return t < cnt ? (int)mem[t] : pos; };
@@ -251,7 +336,7 @@ __global__ __launch_bounds__(64) void proben_fuse_kernel(ProbenArgs a) {
         a.out_keep[o] = piv_row;
         for (int c4 = 0; c4 < 4; ++c4) a.out_boxes[o * 4 + c4] = out_coord[c4];
     }
-    if (lane == 0) a.out_counts[img] = ncl;
+    if (tid == 0) a.out_counts[img] = ncl;
 }
 
 struct PackArgs {
@@ -363,7 +448,10 @@ extern "C" int pe_proben_fuse_batch(const double* boxes, const double* scores, c
                  "pe_proben_fuse_batch: max_rows_per_image %d not in [1,2048]", max_rows_per_image);
     const int R = (max_rows_per_image + 1) & ~1;  // keep the int/short/byte carves 8-byte aligned
     const int L = score_mode == PE_SCORE_PROBEN ? num_classes + 1 : (score_mode == PE_SCORE_PROBEN_BINARY ? 2 : 0);
-    const size_t lds = (size_t)R * (8 * (6 + L + 5) + 4 + 4 + 4 * 2 + 1) + 16;
+    const size_t lds_seq = (size_t)R * (8 * (6 + L + 5) + 4 + 4 + 4 * 2 + 1) + 16;
+    const size_t lds_bits = lds_seq + (size_t)R * ((R + 63) / 64) * 16;        // + the two bit matrices
+    const bool bits = lds_bits <= 160 * 1024;
+    const size_t lds = bits ? lds_bits : lds_seq;
     if (lds > 160 * 1024) {
         pe::set_error("pe_proben_fuse_batch: %zu bytes of LDS needed (> 160 KiB); lower max_rows_per_image", lds);
         return PE_ERR_UNSUPPORTED;
@@ -371,14 +459,18 @@ extern "C" int pe_proben_fuse_batch(const double* boxes, const double* scores, c
     ProbenArgs a{boxes, scores, probs, variances, classes, offsets, row_counts, passthrough, num_images, num_classes, R,
                  score_mode, box_mode, iou_thresh, frame_w, frame_h,
                  out_boxes, out_scores, out_classes, out_keep, out_counts};
+    const void* fn = bits ? reinterpret_cast<const void*>(proben_fuse_kernel<true>) : reinterpret_cast<const void*>(proben_fuse_kernel<false>);
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(proben_fuse_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {
             pe::set_error("pe_proben_fuse_batch: cannot raise dynamic LDS to %zu: %s", lds, hipGetErrorString(e));
             return PE_ERR_HIP;
         }
     }
-    hipLaunchKernelGGL(proben_fuse_kernel, dim3(num_images), dim3(64), lds, (hipStream_t)stream, a);
+    if (bits)
+        hipLaunchKernelGGL(proben_fuse_kernel<true>, dim3(num_images), dim3(kFuseThreads), lds, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(proben_fuse_kernel<false>, dim3(num_images), dim3(kFuseThreads), lds, (hipStream_t)stream, a);
     PE_CHECK_LAUNCH("pe_proben_fuse_batch");
     return PE_OK;
 }

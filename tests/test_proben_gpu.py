@@ -84,9 +84,10 @@ def test_hip_matches_oracle_batched(sm, bm, kdet):
 
 @pytest.mark.parametrize("sm,bm", [("probEn", "v-avg"), ("avg", "s-avg"), ("max", "avg"), ("probEn", "argmax")])
 def test_image_bound_moves_no_bit(sm, bm):
-    """The per-image row bound only sizes the LDS carve (csrc/proben.hip keeps every row's geometry, logs, box, 1 / variance and
-    class id there): the detectors' bound (the longest image here) and 1100 rows (147 KB, above the 64 KiB default) give the same
-    outputs; a bound that does not fit 160 KiB is refused, not truncated."""
+    """The per-image row bound sizes the LDS carve and picks the clustering form of csrc/proben.hip: with the detectors' bound (the
+    longest image here) the pair tests go into two bit matrices and wave 0 walks those; at 1100 rows (147 KB) the matrices do not
+    fit and the walk computes the IoUs on the way, one pivot after the other.  The same outputs; a bound that does not fit 160 KiB
+    at all is refused, not truncated."""
     from proben_amd import _lib, fusion as F
     per_image = synth_batch(40, seed=23, kdet=3)
     b, s, p, v, c, offs = F.pack_infos(per_image)
