@@ -71,6 +71,7 @@ def parse(argv=None):
     ap.add_argument("--conv-policy", type=int, default=-1, help="A/B: tile_bits of pe_test_set_conv_policy (csrc/test_hooks.h; default 329)")
     ap.add_argument("--roi-sort", type=int, default=1, help="0: ROIAlign takes the proposals in RPN order (A/B; identical results)")
     ap.add_argument("--roi-fast", type=int, default=1, help="0: ROIAlign's per-lane form instead of the wave-uniform form (A/B; identical results)")
+    ap.add_argument("--nms-presorted", type=int, default=1, help="0: batched NMS always runs its sorting network (A/B; identical results)")
     ap.add_argument("--wd9-mode", type=int, default=-1,
                     help="A/B (csrc/test_hooks.h): 0 = two-wave weights-direct kernels only (csrc/conv_wd.h), 1 = persistent one-wave-per-SIMD "
                          "kernel for the pure 3x3 launches, 8 = for the fused RPN head, 9 = both; -1 = the library's default (9)")
@@ -518,6 +519,9 @@ def main(argv=None):
     if not args.roi_sort:
         from proben_amd import layers as _layers
         _layers.ROI_SORT = False
+    if not args.nms_presorted:
+        from proben_amd import _lib
+        _lib.test_hooks().pe_test_set_nms_presorted(0)
     if args.roi_fast != 1:
         from proben_amd import _lib
         _lib.test_hooks().pe_test_set_roi_fast(args.roi_fast)

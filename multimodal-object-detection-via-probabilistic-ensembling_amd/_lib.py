@@ -55,7 +55,7 @@ _RESTYPE = {"pe_last_error": ctypes.c_char_p, "pe_nms_scratch_bytes": ctypes.c_s
 
 
 # exported for tests/ and scripts/ only (csrc/test_hooks.h) - not in include/proben_hip.h
-TEST_HOOKS = {"pe_test_set_conv_policy": [c_int, c_int], "pe_test_set_wd9_mode": [c_int], "pe_test_wd9_takes": [c_int] * 5, "pe_test_wd9_head_takes": [c_int] * 3, "pe_test_set_wd9_wgs": [c_int, c_int], "pe_test_set_ring_wgs": [c_int], "pe_test_set_ring_ablation": [c_int], "pe_test_set_roi_fast": [c_int]}
+TEST_HOOKS = {"pe_test_set_conv_policy": [c_int, c_int], "pe_test_set_wd9_mode": [c_int], "pe_test_wd9_takes": [c_int] * 5, "pe_test_wd9_head_takes": [c_int] * 3, "pe_test_set_wd9_wgs": [c_int, c_int], "pe_test_set_ring_wgs": [c_int], "pe_test_set_ring_ablation": [c_int], "pe_test_set_roi_fast": [c_int], "pe_test_set_nms_presorted": [c_int]}
 
 
 class HipLibraryError(RuntimeError):

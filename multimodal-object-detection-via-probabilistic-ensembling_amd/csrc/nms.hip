@@ -18,10 +18,12 @@
 //             (<= 16 chunks for an RPN level instead of 73 for the image, early exit at max_out per class), then the block
 //             re-sorts the survivors by (~score | index) and emits the first max_out.
 #include "common.h"
+#include "test_hooks.h"
 
 namespace {
 
 constexpr int kSortThreads = 1024;
+__device__ int g_presorted_path = 1;     // test hook (pe_test_set_nms_presorted): 0 = always run the sorting network
 
 __device__ __forceinline__ unsigned ordered_desc(float s) {
     s += 0.0f;  // -0 -> +0
@@ -94,7 +96,68 @@ __global__ __launch_bounds__(kSortThreads) void nms_sort_kernel(NmsArgs a) {
     }
     atomicAdd(&cnt_s, local_cnt);
     __syncthreads();
+    // Already in order?  The RPN hands over every level's top-k in score order, the levels one after the other: the live keys
+    // (class | ~score | row) are strictly increasing as they stand and the 91 passes of the network below (n_pad = 8192) would only
+    // move the dead rows' ~0 keys to the end.  Each thread takes n_pad / 1024 CONSECUTIVE keys into registers and checks its own
+    // stretch; a prefix maximum over the threads' last live keys checks the seams (an out-of-order pair across a seam has the later
+    // key <= the maximum of everything before it); a prefix sum of the live counts gives the compaction offsets.  In order: the
+    // live keys are written back closed up, the rest filled with ~0 - exactly the network's result (the keys are unique).
+    bool presorted = false;
+    if (g_presorted_path) {
+        constexpr int EMAX = 16;                   // n_pad <= 16384 = 1024 threads x 16
+        const int E = a.n_pad / kSortThreads;      // 0 when n_pad < 1024: not worth it, sort
+        __shared__ unsigned long long wave_max[kSortThreads / 64];
+        __shared__ int wave_sum[kSortThreads / 64];
+        __shared__ int bad_s;
+        if (tid == 0) bad_s = 0;
+        unsigned long long mine[EMAX];
+        unsigned long long first = ~0ull, last = 0ull;   // live keys are < ~0 and, past the first row, > 0 (row index bits)
+        int live = 0;
+        bool bad = false, any = false;
+        if (E > 0) {
+#pragma unroll
+            for (int j = 0; j < EMAX; ++j) {
+                unsigned long long k = ~0ull;
+                if (j < E) k = keys[tid * E + j];
+                mine[j] = k;
+                if (k != ~0ull) {
+                    if (any && k <= last) bad = true;
+                    if (!any) first = k;
+                    last = k; any = true; ++live;
+                }
+            }
+        }
+        // inclusive scans over the block: live counts (sum) and last live keys (max; 0 = none so far)
+        int ps = live;
+        unsigned long long pm = any ? last : 0ull;
+        for (int o = 1; o < 64; o <<= 1) {
+            const int vs = __shfl_up(ps, o);
+            const unsigned long long vm = __shfl_up(pm, o);
+            if ((tid & 63) >= o) { ps += vs; pm = vm > pm ? vm : pm; }
+        }
+        if ((tid & 63) == 63) { wave_sum[tid >> 6] = ps; wave_max[tid >> 6] = pm; }
+        __syncthreads();
+        int off = ps - live;                                  // exclusive within the wave
+        unsigned long long before = __shfl_up(pm, 1);         // maximum of the lanes before this one (wave-local)
+        if ((tid & 63) == 0) before = 0ull;
+        for (int w = 0; w < (tid >> 6); ++w) { off += wave_sum[w]; before = wave_max[w] > before ? wave_max[w] : before; }
+        if (any && before != 0ull && first <= before) bad = true;
+        // (a live key of 0 can only be row 0 of class 0 with the best possible score: it is the very first key or out of order;
+        //  `before` = 0 then means "nothing before" only for thread 0, and a real 0 before a later key never violates the order)
+        if (bad) bad_s = 1;
+        __syncthreads();
+        presorted = E > 0 && bad_s == 0;
+        if (presorted) {
+            const int nvv = cnt_s;
+#pragma unroll
+            for (int j = 0; j < EMAX; ++j)
+                if (j < E && mine[j] != ~0ull) keys[off++] = mine[j];      // every thread read its stretch before the barrier above
+            for (int i = nvv + tid; i < a.n_pad; i += kSortThreads) keys[i] = ~0ull;
+            __syncthreads();
+        }
+    }
     // bitonic sort ascending
+    if (!presorted)
     for (int k = 2; k <= a.n_pad; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
             for (int i = tid; i < a.n_pad; i += kSortThreads) {
@@ -282,6 +345,11 @@ __global__ __launch_bounds__(kScanThreads) void nms_scan_order_kernel(NmsArgs a)
 }
 
 }  // namespace
+
+extern "C" int pe_test_set_nms_presorted(int on) {
+    const int v = on ? 1 : 0;
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_presorted_path), &v, sizeof(int));
+}
 
 extern "C" size_t pe_nms_scratch_bytes(int32_t B, int32_t n_max) {
     const size_t words = ((size_t)n_max + 63) / 64;

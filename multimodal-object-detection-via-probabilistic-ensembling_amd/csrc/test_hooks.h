@@ -29,6 +29,9 @@ int pe_test_set_wd9_wgs(int pure, int tail);
 int pe_test_set_ring_wgs(int wgs);
 /* ablation builds of the ring kernel (csrc/conv1x1_ring.hip RingArgs::abl; non-zero = wrong results, timing only) */
 int pe_test_set_ring_ablation(int bits);
+/* batched NMS: 1 (default) = input whose live rows are already in (class, score descending, row) order skips the sorting network
+ * (the RPN's hand-over), 0 = the network always runs (same result; A/B and the identity test).  Synchronises the device. */
+int pe_test_set_nms_presorted(int on);
 /* ROIAlign (fp16, C == 256): 1 (default) = the wave-uniform form, 0 = the per-lane form for every launch (same bits; A/B and the identity test) */
 int pe_test_set_roi_fast(int on);
 #ifdef __cplusplus

@@ -603,6 +603,60 @@ def test_nms_empty_and_float_class_ids(L):
     np.testing.assert_array_equal(got, O.batched_nms_f32(b.numpy(), s.numpy(), c.numpy(), 0.5))
 
 
+@pytest.mark.parametrize("case", ["rpn_like", "dead_rows", "ties", "seam_swap", "class_swap", "random", "short"])
+def test_nms_presorted_input_skips_the_network_with_the_same_result(L, case):
+    """csrc/nms.hip::nms_sort_kernel leaves the sorting network out when the live rows already stand in (class, score descending,
+    row) order - the RPN's hand-over: every level's top-k in score order, levels in order.  Against the network (hook off): the same
+    keep lists, for input that is in order (with dead rows in between, with score ties), for input that is out of order by ONE pair
+    (inside a thread's stretch, across the seam of two threads' stretches, across classes), for random input and below 1024 rows."""
+    from oracle import nms as O
+    from proben_amd import _lib
+    H = _lib.test_hooks()
+    g = torch.Generator().manual_seed(sum(map(ord, case)))
+    B, per, levels = 3, 900, 5
+    n = 300 if case == "short" else per * levels + 168                       # 4668 -> n_pad 8192: 8 keys per thread
+    b = torch.stack([rand_boxes(g, n, span=700.0, wh=160.0) for _ in range(B)])
+    s = torch.rand(B, n, generator=g)
+    c = torch.zeros(B, n, dtype=torch.int32)
+    valid = torch.ones(B, n, dtype=torch.uint8)
+    if case != "random":
+        for i in range(B):
+            for l in range(levels + 1):
+                lo, hi = l * per, min((l + 1) * per, n)
+                if lo >= n:
+                    break
+                c[i, lo:hi] = l
+                s[i, lo:hi] = torch.sort(s[i, lo:hi], descending=True).values
+        if case == "dead_rows":
+            valid = (torch.rand(B, n, generator=g) > 0.1).to(torch.uint8)
+            valid[:, 0] = 0
+        if case == "ties":
+            s = (s * 40).round() / 40                                        # long runs of equal scores: the row index decides
+        if case == "seam_swap":
+            s[0, 7], s[0, 8] = s[0, 8].clone(), s[0, 7].clone()             # rows 7 | 8: two threads' stretches
+            s[1, 2], s[1, 3] = s[1, 3].clone(), s[1, 2].clone()             # inside one stretch
+            assert float(s[0, 8]) > float(s[0, 7]) and float(s[1, 3]) > float(s[1, 2])
+        if case == "class_swap":
+            c[2, per - 1], c[2, per] = 1, 0
+    else:
+        c = torch.randint(0, 5, (B, n), generator=g).int()
+    args = (b.cuda(), s.cuda(), c.cuda(), None, valid.cuda(), 0.7, 0, 1000)
+    try:
+        H.pe_test_set_nms_presorted(1)
+        keep1, cnt1 = L.nms_batched_raw(*args)
+        H.pe_test_set_nms_presorted(0)
+        keep0, cnt0 = L.nms_batched_raw(*args)
+    finally:
+        H.pe_test_set_nms_presorted(1)
+    assert torch.equal(cnt0, cnt1) and int(cnt0.min()) > 0
+    for i in range(B):
+        assert torch.equal(keep0[i, : int(cnt0[i])], keep1[i, : int(cnt1[i])])
+    i = B - 1                                                                 # and one image against the oracle
+    live = valid[i].bool()
+    want = O.batched_nms_f32(b[i][live].numpy(), s[i][live].numpy(), c[i][live].numpy(), 0.7)[:1000]
+    np.testing.assert_array_equal(keep1[i, : int(cnt1[i])].cpu().numpy(), torch.nonzero(live).flatten().numpy()[want])
+
+
 def test_nms_batched_raw_valid_mask_and_counts(L):
     from oracle import nms as O
     g = torch.Generator().manual_seed(21)
