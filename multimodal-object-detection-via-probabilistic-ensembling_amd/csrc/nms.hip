@@ -53,6 +53,7 @@ struct NmsArgs {
     int words;
     int32_t* out_keep;     // [B, max_out]
     int32_t* out_counts;   // [B]
+    int merge;             // scan + order: the LDS holds the survivors' keys behind the kept lists (merge by rank instead of a sort)
 };
 
 __global__ __launch_bounds__(kSortThreads) void nms_sort_kernel(NmsArgs a) {
@@ -241,14 +242,20 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(NmsArgs a) {
 //   2. lane l fetches the DIAGONAL word of row 64c+l and the chunk is resolved in registers with scalar readlanes;
 //   3. survivors are appended to the segment's kept list and flagged; a segment stops at max_out survivors (no class can
 //      place more than that in the final top max_out).
-// Phase 2: the flagged rows' (~score | input index) keys are bitonic-sorted by the whole block; the first max_out leave.
+// Phase 2: the survivors leave in (~score | input index) order, the first max_out of them.  A segment's kept list already is in
+// that order, so with few segments (<= 16: the RPN's five levels, the FLIR heads' three classes) every survivor's place is its
+// place in its own list plus, per other segment, the number of that segment's survivors in front of it - a binary search over the
+// survivors' keys in LDS (~10 probes x 4 lists) instead of the 91 passes of a sorting network over n_pad keys.  More segments (the
+// 80-class head) or no room for the keys: the flagged rows' keys are bitonic-sorted by the whole block.
 constexpr int kScanThreads = 1024;
+constexpr int kMergeSegs = 16;
 __global__ __launch_bounds__(kScanThreads) void nms_scan_order_kernel(NmsArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // phase 1 layout: kept_pos [n_max] u16 | flags [n_pad / 32] u32;  phase 2: keys [n_pad] u64 over the same bytes
     unsigned short* kept_pos = reinterpret_cast<unsigned short*>(smem);
     unsigned* flags = reinterpret_cast<unsigned*>(smem + (((size_t)a.n_max * 2 + 15) & ~(size_t)15));
     __shared__ int total_s;
+    __shared__ int seg_p0_s[kMergeSegs], seg_kept_s[kMergeSegs];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nv = a.nvalid[b];
     const int nseg = a.nseg[b];
@@ -274,15 +281,25 @@ __global__ __launch_bounds__(kScanThreads) void nms_scan_order_kernel(NmsArgs a)
         int kept = 0;
         for (int c = p0 >> 6; c <= ((p1 - 1) >> 6) && kept < a.max_out; ++c) {
             const int i0 = c * 64;
-            unsigned long long rem = 0;
-            for (int k = lane; k < kept; k += 64) {
-                const int p = kp[k];
-                if ((p >> 6) < c) rem |= mk[(size_t)p * a.words + c];
-            }
-            for (int o = 32; o > 0; o >>= 1) rem |= __shfl_xor(rem, o);
             const int row = i0 + lane;
             const bool mine = row >= p0 && row < p1;
-            const unsigned long long diag = mine ? mk[(size_t)row * a.words + c] : 0ull;
+            const unsigned long long diag = mine ? mk[(size_t)row * a.words + c] : 0ull;     // in flight together with the gather below
+            unsigned long long rem = 0;
+            constexpr int GB = 16;      // a lane's loads of one batch: all issued before the first is waited for (a segment that stops
+            for (int k0 = 0; k0 < kept; k0 += 64 * GB) {     // at max_out <= 1024 survivors is ONE batch = one memory latency per chunk;
+                int pp[GB];                                  // one load per loop trip cost sixteen of them: 27 k cycles per chunk)
+#pragma unroll
+                for (int u = 0; u < GB; ++u) {
+                    const int k = k0 + u * 64 + lane;
+                    pp[u] = k < kept ? (int)kp[k] : 0x7FFFFFFF;
+                }
+                unsigned long long v[GB];
+#pragma unroll
+                for (int u = 0; u < GB; ++u) v[u] = (pp[u] >> 6) < c ? mk[(size_t)pp[u] * a.words + c] : 0ull;
+#pragma unroll
+                for (int u = 0; u < GB; ++u) rem |= v[u];
+            }
+            for (int o = 32; o > 0; o >>= 1) rem |= __shfl_xor(rem, o);
             const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
             const int b_lo = max(p0 - i0, 0), b_hi = min(p1 - i0, 64);
             unsigned long long keepmask = 0;
@@ -303,9 +320,46 @@ __global__ __launch_bounds__(kScanThreads) void nms_scan_order_kernel(NmsArgs a)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the kept list is re-read by other lanes of this wave
             __builtin_amdgcn_wave_barrier();
         }
-        if (lane == 0) atomicAdd(&total_s, kept);
+        if (lane == 0) {
+            atomicAdd(&total_s, kept);
+            if (sgi < kMergeSegs) { seg_p0_s[sgi] = p0; seg_kept_s[sgi] = kept; }
+        }
     }
     __syncthreads();
+    if (a.merge && nseg <= kMergeSegs) {
+        // ---- phase 2, merge by rank ----
+        unsigned long long* key2 = reinterpret_cast<unsigned long long*>(smem + (((((size_t)a.n_max * 2 + 15) & ~(size_t)15) + (size_t)a.n_pad / 8 + 15) & ~(size_t)15));
+        int off[kMergeSegs + 1];
+        off[0] = 0;
+#pragma unroll
+        for (int s = 0; s < kMergeSegs; ++s) off[s + 1] = off[s] + (s < nseg ? seg_kept_s[s] : 0);
+        const int total = total_s;
+        for (int g = tid; g < total; g += kScanThreads) {
+            int s = 0;
+            while (g >= off[s + 1]) ++s;
+            const int p = kept_pos[seg_p0_s[s] + (g - off[s])];
+            key2[g] = ((unsigned long long)a.sord[(size_t)b * a.n_max + p] << 32) | (unsigned)a.sidx[(size_t)b * a.n_max + p];
+        }
+        __syncthreads();
+        for (int g = tid; g < total; g += kScanThreads) {
+            int s = 0;
+            while (g >= off[s + 1]) ++s;
+            const unsigned long long x = key2[g];
+            int rank = g - off[s];
+            for (int t = 0; t < nseg; ++t) {
+                if (t == s) continue;
+                int lo = off[t], hi = off[t + 1];         // first key of list t that is not < x (keys are unique)
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (key2[mid] < x) lo = mid + 1; else hi = mid;
+                }
+                rank += lo - off[t];
+            }
+            if (rank < a.max_out) a.out_keep[(size_t)b * a.max_out + rank] = (int)(x & 0xFFFFFFFFu);
+        }
+        if (tid == 0) a.out_counts[b] = min(total, a.max_out);
+        return;
+    }
     // ---- phase 2: keys of the flagged rows (flags are read into registers before the key array overwrites them) ----
     unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);
     constexpr int KPT = 16;   // n_pad <= 16384 = 1024 threads x 16
@@ -403,7 +457,10 @@ extern "C" int pe_nms_batched(const float* boxes, const float* scores, const int
     PE_CHECK_LAUNCH("pe_nms_batched(sort)");
     hipLaunchKernelGGL(nms_mask_kernel, dim3(a.words, a.words, B), dim3(64), 0, st, a);
     PE_CHECK_LAUNCH("pe_nms_batched(mask)");
-    const size_t lds2 = std::max((size_t)a.n_pad * 8, (((size_t)n_max * 2 + 15) & ~(size_t)15) + (size_t)a.n_pad / 8 + 16);
+    const size_t lists = (((((size_t)n_max * 2 + 15) & ~(size_t)15) + (size_t)a.n_pad / 8 + 15) & ~(size_t)15);   // kept lists + flags
+    size_t lds2 = std::max((size_t)a.n_pad * 8, lists + 16);
+    a.merge = lists + (size_t)n_max * 8 + 256 <= 160 * 1024;       // + the survivors' keys (at most one per row)
+    if (a.merge) lds2 = std::max(lds2, lists + (size_t)n_max * 8);
     PE_ENSURE_LDS(nms_scan_order_kernel, lds2 + 256, "pe_nms_batched(scan + order)");   // + the kernel's static LDS
     hipLaunchKernelGGL(nms_scan_order_kernel, dim3(B), dim3(kScanThreads), lds2, st, a);
     PE_CHECK_LAUNCH("pe_nms_batched(scan + order)");
