@@ -91,15 +91,11 @@ struct PilArgs {
 
 __device__ __forceinline__ int clip8(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
 
+// one output pixel, both passes from memory (the form of rounds 1-4; now the path of tiles whose source window does not fit the LDS)
 template <int NCH, bool FLIP>
-__global__ void preprocess_pil_kernel(PilArgs a) {
-    const unsigned char* src = a.src + (size_t)blockIdx.z * a.src_h * a.src_w * a.src_c;
-    _Float16* dst = a.dst + (size_t)blockIdx.z * a.pad_h * a.pad_w * 4;
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y;
-    if (x >= a.pad_w) return;
+__device__ __forceinline__ half4 pil_pixel(const PilArgs& a, const unsigned char* src, int x, int y) {
     half4 o = {0, 0, 0, 0};
-    if (y < a.dst_h && x < a.dst_w) {
+    {
         const int32_t* xt = a.xtab + (size_t)x * (2 + a.xk);
         const int32_t* yt = a.ytab + (size_t)y * (2 + a.yk);   // wave-uniform: scalar loads
         const int xmin = xt[0], nx = xt[1], ymin = yt[0], ny = yt[1];
@@ -123,7 +119,91 @@ __global__ void preprocess_pil_kernel(PilArgs a) {
 #pragma unroll
         for (int c = 0; c < NCH; ++c) o[c] = (_Float16)(((float)clip8(accv[c] >> 22) - a.mean[c]) * a.inv_std[c]);
     }
-    *reinterpret_cast<half4*>(dst + ((size_t)y * a.pad_w + x) * 4) = o;
+    return o;
+}
+
+// A workgroup makes a 256-column x 16-row tile of the output.  Pillow's horizontal pass produces a uint8 image of the SOURCE's
+// height; the tile needs rows r_lo .. r_hi of it (13 of them for 16 output rows at the detectors' 1.5625x), each computed ONCE per
+// column into LDS (thread = column: its tap table row stays in registers), and the vertical pass reads them back - the per-pixel
+// form recomputed the horizontal pass for every vertical tap: 27 single-byte loads + the table reads per output pixel, ~40 vector
+// memory instructions, which is what bound it (0.20 ms for 32 frames; TA-issue, not bytes).  Same integer arithmetic, same bits.
+constexpr int PIL_TX = 256, PIL_TY = 16, PIL_MAXR = 16, PIL_MAXK = 8;
+template <int NCH, bool FLIP>
+__global__ __launch_bounds__(PIL_TX) void preprocess_pil_kernel(PilArgs a) {
+    __shared__ unsigned hbuf[PIL_MAXR][PIL_TX];
+    const unsigned char* src = a.src + (size_t)blockIdx.z * a.src_h * a.src_w * a.src_c;
+    _Float16* dst = a.dst + (size_t)blockIdx.z * a.pad_h * a.pad_w * 4;
+    const int tid = threadIdx.x;
+    const int x = blockIdx.x * PIL_TX + tid;
+    const int y0 = blockIdx.y * PIL_TY;
+    const int rows = min(PIL_TY, a.pad_h - y0);
+    const bool col_live = x < a.dst_w;
+    int r_lo = 0, nr = 0;
+    if (y0 < a.dst_h && blockIdx.x * PIL_TX < a.dst_w) {      // the tile has resized pixels
+        const int yl = min(y0 + PIL_TY, a.dst_h);
+        int lo = 0x7FFFFFFF, hi = 0;     // the union of the tile rows' windows (the tables carry trimmed windows: not monotone row to row)
+        for (int y = y0; y < yl; ++y) {
+            const int32_t* t = a.ytab + (size_t)y * (2 + a.yk);   // wave-uniform: scalar loads
+            lo = min(lo, t[0]);
+            hi = max(hi, t[0] + t[1]);
+        }
+        r_lo = lo;
+        nr = hi - lo;
+    }
+    const bool tiled = nr > 0 && nr <= PIL_MAXR && a.xk <= PIL_MAXK;     // workgroup-uniform
+    if (tiled) {
+        if (col_live) {
+            const int32_t* xt = a.xtab + (size_t)x * (2 + a.xk);
+            const int xmin = xt[0], nx = xt[1];
+            int kx[PIL_MAXK];
+#pragma unroll
+            for (int i = 0; i < PIL_MAXK; ++i) kx[i] = i < nx ? xt[2 + i] : 0;
+            for (int r = 0; r < nr; ++r) {
+                const unsigned char* row = src + ((size_t)(r_lo + r) * a.src_w + xmin) * a.src_c + a.ch0;
+                int acch[NCH];
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) acch[c] = 1 << 21;
+#pragma unroll
+                for (int i = 0; i < PIL_MAXK; ++i)
+                    if (i < nx) {
+#pragma unroll
+                        for (int c = 0; c < NCH; ++c) acch[c] += (int)row[i * a.src_c + ((FLIP && c < 3) ? 2 - c : c)] * kx[i];
+                    }
+                // the horizontal pass result is a uint8 image.  Byte stores: packing the three with shifts and ORs makes hipcc 7.2 emit
+                // v_ashr_pk_u8_i32 for two of them and OR the third into its UPPER half, which that instruction does not clear
+                // (garbage in channel 2 on gfx950; found by tests/test_ops_gpu.py::test_preprocess_pil_exact_vs_oracle)
+                unsigned char* hb = reinterpret_cast<unsigned char*>(&hbuf[r][tid]);
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) hb[c] = (unsigned char)clip8(acch[c] >> 22);
+            }
+        }
+        __syncthreads();
+    }
+    if (x >= a.pad_w) return;
+    for (int yy = 0; yy < rows; ++yy) {
+        const int y = y0 + yy;
+        half4 o = {0, 0, 0, 0};
+        if (y < a.dst_h && col_live) {
+            if (tiled) {
+                const int32_t* yt = a.ytab + (size_t)y * (2 + a.yk);   // wave-uniform: scalar loads
+                const int ymin = yt[0], ny = yt[1];
+                int accv[NCH];
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) accv[c] = 1 << 21;
+                for (int j = 0; j < ny; ++j) {
+                    const unsigned h = hbuf[ymin - r_lo + j][tid];
+                    const int k = yt[2 + j];
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) accv[c] += (int)((h >> (8 * c)) & 255u) * k;
+                }
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) o[c] = (_Float16)(((float)clip8(accv[c] >> 22) - a.mean[c]) * a.inv_std[c]);
+            } else {
+                o = pil_pixel<NCH, FLIP>(a, src, x, y);
+            }
+        }
+        *reinterpret_cast<half4*>(dst + ((size_t)y * a.pad_w + x) * 4) = o;
+    }
 }
 
 __global__ void maxpool3x3s2_kernel(const _Float16* in, _Float16* out, int N, int H, int W, int C, int Ho, int Wo) {
@@ -229,7 +309,7 @@ extern "C" int pe_preprocess_pack_pil_u8(const void* src, int32_t num_images, in
         a.mean[c] = c < nch ? mean_host[c] : 0.f;
         a.inv_std[c] = c < nch ? 1.f / std_host[c] : 0.f;
     }
-    const dim3 grid(pe::ceil_div(pad_w, 256), pad_h, num_images), block(256);
+    const dim3 grid(pe::ceil_div(pad_w, PIL_TX), pe::ceil_div(pad_h, PIL_TY), num_images), block(PIL_TX);
     hipStream_t st = (hipStream_t)stream;
 #define PE_PIL_LAUNCH(N, F) hipLaunchKernelGGL((preprocess_pil_kernel<N, F>), grid, block, 0, st, a)
     switch (nch * 2 + (flip_rgb ? 1 : 0)) {

@@ -558,10 +558,13 @@ def test_preprocess_float_resize_vs_opencv_restatement(L, case):
     assert np.array_equal(dst.cpu().numpy()[:nh, :nw, :c], want)
 
 
-@pytest.mark.parametrize("case", [(2, 48, 60, 75, 94), (1, 64, 64, 31, 47), (1, 512, 640, 800, 1000), (3, 90, 30, 135, 30)])
+@pytest.mark.parametrize("case", [(2, 48, 60, 75, 94), (1, 64, 64, 31, 47), (1, 512, 640, 800, 1000), (3, 90, 30, 135, 30), (1, 100, 300, 100, 300),
+                                  (1, 64, 600, 64, 100), (2, 40, 700, 100, 300)])
 def test_preprocess_pil_exact_vs_oracle(L, case):
     """3-channel uint8 frames are resized exactly like Pillow (the reference's path, transform.py:92-97): every packed
-    fp16 value equals (pillow_resize(img) - mean) / std computed from the oracle's restatement; padding is zero."""
+    fp16 value equals (pillow_resize(img) - mean) / std computed from the oracle's restatement; padding is zero.  Upscaling and
+    1:1 go through the tiled two-pass kernel (horizontal pass once per source row into LDS), vertical downscaling (more than 16
+    source rows per 16 output rows) and horizontal windows above 8 taps through the per-pixel form of the same kernel."""
     from oracle import resize as R
     n, h, w, nh, nw = case
     img = np.random.default_rng(h + w).integers(0, 256, size=(n, h, w, 3), dtype=np.uint8)
