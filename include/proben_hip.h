@@ -53,8 +53,9 @@ int pe_version(void);
  * float64 boxes / float32 scores and classes out (the reference's torch.Tensor exit).
  * Output rows of image b are written at [offsets[b], offsets[b] + out_counts[b]) in pivot order.
  * out_counts[b] = -1 if the image has more than max_rows_per_image rows.
- * One wavefront per image; max_rows_per_image sizes the per-wavefront LDS slab: (8 * (11 + L) + 17) bytes per row, L = num_classes + 1
- * (probEn), 2 (binary) or 0 - 160 KiB hold 1 195 rows at num_classes 3; a bound that does not fit returns PE_ERR_UNSUPPORTED.
+ * One 1024-thread workgroup per image; max_rows_per_image (R) sizes its LDS slab: (8 * (11 + L) + 17) bytes per row, L = num_classes + 1
+ * (probEn), 2 (binary) or 0 - 160 KiB hold 1 195 rows at num_classes 3; a bound that does not fit returns PE_ERR_UNSUPPORTED.  With
+ * 16 * ceil(R / 64) more bytes per row (R <= ~560 at num_classes 3) the pair tests go into two bit matrices first; the results are the same.
  * ------------------------------------------------------------------------------------------- */
 int pe_proben_fuse_batch(const double* boxes,     /* [Ntot,4] xyxy */
                          const double* scores,    /* [Ntot] */
