@@ -229,7 +229,8 @@ __global__ __launch_bounds__(256) void roi_align_kernel(RoiArgs a) {
             const unsigned step_c = (unsigned)a.C * 2u, step_r = (unsigned)(W - nxm + 1) * a.C * 2u;
             // x / count, correctly rounded, in 3 instead of ~10 instructions: with y = RN(1 / count), q = RN(x * y) is refined once
             // through the exact residual (Markstein).  Checked exhaustively against IEEE division over all 2^23 significands for every
-            // count = g1 * g2, g <= 22 (the tables hold at most 20 pixels per bin, i.e. a sampling grid below 20); beyond: divide.
+            // count = g1 * g2, g <= 22 (tests/csrc/div_check.c, run by tests/test_roi_division_cpu.py; the tables hold at most 20 pixels
+            // per bin, i.e. a sampling grid below 20); beyond: divide.
             const bool short_div = grid_h <= 22 && grid_w <= 22;
             const float rcp = 1.f / count;
             constexpr int MLP = ROI_MLP;
