@@ -1,15 +1,15 @@
-// ProbEn late fusion for gfx950: ONE WAVEFRONT PER IMAGE, whole per-image state in LDS.
+// ProbEn late fusion for gfx950: ONE WORKGROUP PER IMAGE (one wavefront in rounds 1-4), whole per-image state in LDS.
 //
 // Replaces the reference's per-image NumPy loop (demo/FLIR/demo_probEn.py:92-187 nms_bayesian,
 // :32-42 bayesian_fusion_multiclass, :24-30 bayesian_fusion, :73-77 weighted_box_fusion,
 // :20-22 avg_bbox_fusion).  float64 throughout (the reference's NumPy dtype); compiled with
 // -ffp-contract=off so IoU decisions round exactly like the reference's separate mul/add/div.
 //
-// Kernel shape: the greedy clustering is inherently sequential in the pivot (<= N pivots per
-// image), so parallelism comes from (a) 64 lanes scoring the pivot against 64 candidates per
-// step with a ballot-compacted member list, (b) per-row logs / geometry precomputed in parallel,
-// (c) the fusion formulas run AFTER the clustering, one lane per cluster (the clusters do not depend on them),
-// (d) thousands of images in flight (one wave each, <= 32 waves per CU).  Per image the HBM
+// Kernel shape: the greedy clustering is sequential in the pivot (<= N pivots per image) but its IoU tests are not - they
+// use the rows' own geometry -, so parallelism comes from (a) the pair tests as ballots into bit matrices by all waves and a
+// register-resident walk over them (or, when the matrices do not fit, 64 lanes scoring the pivot against 64 candidates per step),
+// (b) per-row ranks / logs / geometry a thread per row, (c) the fusion formulas AFTER the clustering, a thread per cluster,
+// (d) one workgroup per image, any number of images per launch.  Per image the HBM
 // traffic is N*(4+1+K+1)*8 + N*4 bytes in and M*(32+4+4+4) bytes out; everything else stays in LDS.
 #include "common.h"
 

@@ -3,7 +3,7 @@
 Mirrors the reference's call surface (demo/FLIR/demo_probEn.py):
   fusion(method, info_1, info_2, info_3='')   :189-196  (one image, Python lists in)
 and adds the batched form the MI355X path actually uses:
-  fuse_batch(...)                             one launch, one wavefront per image.
+  fuse_batch(...)                             one launch, one 1024-thread workgroup per image.
 The arithmetic lives in csrc/proben.hip behind pe_proben_fuse_batch.
 """
 import numpy as np
