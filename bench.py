@@ -148,6 +148,24 @@ def comm_active():
     return dist.is_available() and dist.is_initialized()
 
 
+def count_collectives():
+    """Wraps torch.distributed's tensor collectives with a counter (bench.py only: the line reports how many the timed loop issued
+    per step; the product documents ONE).  Returns the counter dict {"n": calls so far}."""
+    import torch.distributed as dist
+    c = {"n": 0}
+    for name in ("all_gather_into_tensor", "all_gather", "all_reduce", "broadcast", "reduce_scatter_tensor", "all_to_all_single", "gather", "reduce"):
+        fn = getattr(dist, name, None)
+        if fn is None or getattr(fn, "_counted", False):
+            continue
+
+        def wrap(*a, _fn=fn, **k):
+            c["n"] += 1
+            return _fn(*a, **k)
+        wrap._counted = True
+        setattr(dist, name, wrap)
+    return c
+
+
 def make_step(models, frames, cfg, world, with_comm=True, concurrent=True, stagger=0, feeder=None):
     import torch
     from proben_amd.pipeline import FramePairPipeline
@@ -382,7 +400,8 @@ def proben_micro(device, B=4096, reps=20):
     nbytes = n_in * ((4 + 1 + 3 + 1) * 8 + 4) + n_out * (4 + 1 + 1) * 4
     return {"images": B, "rows_in_mean": round(n_in / B, 1), "rows_out_mean": round(n_out / B, 1), "ms_per_launch": round(sec * 1e3, 4),
             "us_per_image": round(sec / B * 1e6, 4), "images_per_s": round(B / sec), "algorithmic_gbs": round(nbytes / sec / 1e9, 2),
-            "note": "one wavefront per image, float64; latency / LDS bound, not HBM bound (the whole batch is " + str(round(nbytes / 1e6, 1)) + " MB)"}
+            "note": "one 1024-thread workgroup per image (pair tests into LDS bit matrices, one wave walks the rows, a thread per cluster), float64; "
+                    "latency / LDS bound, not HBM bound (the whole batch is " + str(round(nbytes / 1e6, 1)) + " MB)"}
 
 
 class BoardPower:
@@ -413,8 +432,9 @@ class BoardPower:
         except Exception:
             self.proc = None
 
-    def result(self, w0, w1, units):
-        """w0 / w1: time.time() at the two ends of the timed region."""
+    def result(self, w0, w1, units, windows=None):
+        """w0 / w1: time.time() at the two ends of the timed region; windows: [(start, end)] wall-clock sub-windows of it -> the median
+        shader clock and board power of the samples inside each (None where no sample fell)."""
         import signal
         if self.proc is None:
             return {"available": False, "cap_w": self.cap}
@@ -437,14 +457,19 @@ class BoardPower:
             os.unlink(self.path)
         except Exception:
             pass
+        all_rows = rows
         rows = [r for r in rows if w0 <= r[0] and r[0] + 0.1 <= w1]     # a sample is taken shortly AFTER its stamp
         if not rows:
             return {"available": False, "cap_w": self.cap}
-        med = lambda v: sorted(v)[len(v) // 2]
+        med = lambda v: sorted(v)[len(v) // 2] if v else None
+        per_window = None
+        if windows:
+            per_window = {"sclk_mhz": [med([r[2] for r in all_rows if a <= r[0] + 0.05 < b and r[2] is not None]) for a, b in windows],
+                          "board_w": [med([r[1] for r in all_rows if a <= r[0] + 0.05 < b]) for a, b in windows]}
         w = med([r[1] for r in rows])
         clk = [r[2] for r in rows if r[2] is not None]
         return {"available": True, "board_w_median": w, "board_w_max": max(r[1] for r in rows), "cap_w": self.cap,
-                "sclk_mhz_median": med(clk) if clk else None, "samples": len(rows),
+                "sclk_mhz_median": med(clk) if clk else None, "samples": len(rows), "per_window": per_window,
                 "joules_per_unit": round(w * (w1 - w0) / units, 3),
                 "source": "rocm-smi --showpower --showclocks polled by a helper process during the timed region (socket package power)"}
 
@@ -553,13 +578,37 @@ def main(argv=None):
     power = BoardPower(local) if rank == 0 and not args.no_power else None
     if power is not None:
         power.start()
+    # The timed region is cut into up to 5 equal sub-windows by EVENTS (recorded on every stream the step launches on; no
+    # synchronisation inside the region): `value_windows` in the line shows whether a run-to-run difference is a clock ramp at the
+    # start of the region or the box.
+    streams = [torch.cuda.current_stream()] + list(getattr(step.pipe, "streams", None) or [])
+    n_win = min(5, args.steps)
+    bounds = [round(i * args.steps / n_win) for i in range(n_win + 1)]
+    marks = []
+
+    def mark():
+        evs = [torch.cuda.Event(enable_timing=True) for _ in streams]
+        for e, st in zip(evs, streams):
+            e.record(st)
+        marks.append(evs)
+    calls = count_collectives() if (world > 1 or comm_active()) else None
     fence()
     w0, t0 = time.time(), time.perf_counter()
-    for _ in range(args.steps):
+    mark()
+    if calls is not None:
+        calls["n"] = 0
+    for i in range(args.steps):
         out = step()
+        if i + 1 in bounds[1:]:
+            mark()
+    n_coll = calls["n"] if calls is not None else 0
     fence()
     dt = time.perf_counter() - t0
     w1 = time.time()
+    # boundary b's offset from the start of the region = the LATEST of the streams' events (ms)
+    offs = [max(m0.elapsed_time(m) for m0, m in zip(marks[0], evs)) for evs in marks]
+    win_ms = [offs[i + 1] - offs[i] for i in range(n_win)]
+    win_steps = [bounds[i + 1] - bounds[i] for i in range(n_win)]
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -580,6 +629,8 @@ def main(argv=None):
                        "frames or frame-pairs/sec, 640x512, " + cfg["title"]),
             "value": round(value, 2), "unit": cfg["unit"], "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "value_windows": [round(world * B * n / (ms * 1e-3), 1) if ms > 0 else None for n, ms in zip(win_steps, win_ms)],
+            "window_steps": win_steps,
             "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": f"{cfg['title']}, batch {B} per GPU, R{depth}-FPN x{len(models)}, 640x512 -> 800x1000 (padded 800x1024), "
                                    f"K={cfg['K']}, random-init weights",
@@ -594,10 +645,15 @@ def main(argv=None):
                                               "layers with K >= 512 and Cout % 256 == 0 (res4 / res5 conv1, top lateral, fc1, fc2)")},
         }
         if power is not None:
-            line["power"] = power.result(w0, w1, B * args.steps)    # rank 0's board, rank 0's units
+            line["power"] = power.result(w0, w1, B * args.steps,     # rank 0's board, rank 0's units
+                                         windows=[(w0 + offs[i] * 1e-3, w0 + offs[i + 1] * 1e-3) for i in range(n_win)])
+            pw = (line["power"] or {}).get("per_window")
+            if pw:
+                line["sclk_mhz_windows"] = pw["sclk_mhz"]
         if world > 1 or comm_active():
             line["config"]["collective"] = "one all_gather_into_tensor of the fused rows per step (RCCL)" + ("" if world > 1 else
                                            "; PROBEN_FORCE_DIST: a ONE-rank RCCL group, the collective runs but moves nothing between devices")
+            line["config"]["collective_calls_per_step"] = n_coll / args.steps     # counted at torch.distributed's entry points inside the timed loop
         if not args.no_roofline:
             # rank-local leg: no collective inside (the other ranks are already waiting at the final barrier)
             line["roofline"] = roofline_leg(make_step(models, frames_dev, cfg, world, with_comm=False, concurrent=False), args.layers)

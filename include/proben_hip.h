@@ -134,12 +134,10 @@ int pe_conv_wd_supported(int32_t kernel, int32_t stride, int32_t H, int32_t W, i
  * one tile per workgroup (csrc/conv_wd.h), and one wave per SIMD with 256 accumulators in the AGPRs and PERSISTENT workgroups
  * (csrc/conv_wd9.h: the pure 3x3 and the fused RPN head at image widths 64 / 128 / 256 from 128 tiles of 256 pixels on - the same
  * bits as the two-wave kernels, so the size rule may look at the batch).  pe_bottleneck_tail_wd_f16 always runs on csrc/conv_wd.h.
- * A persistent kernel occupies every CU it runs on for its whole duration.  A caller that runs `streams` detectors concurrently on
- * as many HIP streams (proben_amd/pipeline.py) may say so here.  The hint is validated (1 .. 8) and, since round 5, otherwise
- * ignored: it sized round 4's opt-in persistent tail kernel, which left the library (scripts/lab/conv_wd9_tail.h), and the persistent
- * kernels that ship (csrc/conv_wd9.h, csrc/conv1x1_ring.hip) measured best at one workgroup per CU under one, two and three detector
- * streams (profiles/r04_pipeline_ab_2.txt, r05_pipeline_ab_ring.txt).  Kept for ABI stability.  Never changes results. */
-int pe_conv_wd_set_concurrent_streams(int32_t streams);
+ * A persistent kernel occupies every CU it runs on for its whole duration; the ones that ship (csrc/conv_wd9.h, csrc/conv1x1_ring.hip)
+ * measured best at one workgroup per CU under one, two and three concurrent detector streams (profiles/r04_pipeline_ab_2.txt,
+ * r05_pipeline_ab_ring.txt), so there is nothing for a caller to tune (round 4-5's `pe_conv_wd_set_concurrent_streams` hint, a
+ * validated no-op since its kernel left the library, was removed from the ABI in round 6). */
 /* weight: [Cout][3][3][Cin] fp16 (the layout pe_conv2d_nhwc_f16 takes); packed: Cout*9*Cin halfs */
 int pe_conv_wd_pack_weights(const void* weight, void* packed, int32_t Cout, int32_t Cin, int32_t kernel, void* stream);
 int pe_conv3x3_wd_f16(const void* input, const void* packed_weight, const float* bias, void* output, int32_t N,

@@ -18,7 +18,6 @@ SIGNATURES = {
     "pe_proben_fuse_batch": [c_void_p] * 8 + [c_int] * 5 + [c_double] * 3 + [c_void_p] * 5 + [c_void_p],
     "pe_conv2d_nhwc_f16": [c_void_p] * 5 + [c_int] * 14 + [c_void_p],
     "pe_conv_wd_supported": [c_int] * 6,
-    "pe_conv_wd_set_concurrent_streams": [c_int],
     "pe_conv_wd_pack_weights": [c_void_p] * 2 + [c_int] * 3 + [c_void_p],
     "pe_conv3x3_wd_f16": [c_void_p] * 4 + [c_int] * 7 + [c_void_p],
     "pe_conv_wd_pack_tail": [c_void_p] * 2 + [c_int] * 2 + [c_void_p],
@@ -55,7 +54,7 @@ _RESTYPE = {"pe_last_error": ctypes.c_char_p, "pe_nms_scratch_bytes": ctypes.c_s
 
 
 # exported for tests/ and scripts/ only (csrc/test_hooks.h) - not in include/proben_hip.h
-TEST_HOOKS = {"pe_test_set_conv_policy": [c_int, c_int], "pe_test_set_wd9_mode": [c_int], "pe_test_wd9_takes": [c_int] * 5, "pe_test_wd9_head_takes": [c_int] * 3, "pe_test_set_wd9_wgs": [c_int, c_int], "pe_test_set_ring_wgs": [c_int], "pe_test_set_ring_ablation": [c_int], "pe_test_set_roi_fast": [c_int], "pe_test_set_nms_presorted": [c_int]}
+TEST_HOOKS = {"pe_test_set_conv_policy": [c_int, c_int], "pe_test_set_wd9_mode": [c_int], "pe_test_wd9_takes": [c_int] * 5, "pe_test_wd9_head_takes": [c_int] * 3, "pe_test_set_wd9_wgs": [c_int, c_int], "pe_test_set_ring_wgs": [c_int], "pe_test_set_roi_fast": [c_int], "pe_test_set_nms_presorted": [c_int]}
 
 
 class HipLibraryError(RuntimeError):
@@ -81,9 +80,15 @@ def lib():
     return _lib
 
 
+LAB_HOOKS = {"pe_test_set_ring_ablation": [c_int]}     # exported by the LAB build only (`python -m proben_amd.build --lab`, -DPE_LAB)
+
+
 def test_hooks():
     """The library with the measurement hooks of csrc/test_hooks.h typed (tests/ and scripts/ only)."""
     L = lib()
+    for name, args in LAB_HOOKS.items():
+        if hasattr(L, name):
+            getattr(L, name).argtypes, getattr(L, name).restype = args, ctypes.c_int
     for name, args in TEST_HOOKS.items():
         fn = getattr(L, name)
         fn.argtypes, fn.restype = args, ctypes.c_int

@@ -5,6 +5,12 @@ the library is a plain C-ABI (include/proben_hip.h).
 
 Objects are cached under csrc/_build by source mtime; hipcc cross-compiles
 without a GPU.
+
+    python -m proben_amd.build --lab  builds libproben_hip_lab.so with -DPE_LAB (objects under
+csrc/_build_lab): the product library plus the kernels' MEASUREMENT switches (ablation
+branches that give wrong results, e.g. csrc/conv1x1_ring.hip RingArgs::abl).  Nothing in the
+product, the tests or bench.py loads it; scripts/archive/r05_ring_abl.py does, by pointing
+proben_amd._lib.LIB_PATH at it before the first call.
 """
 import os
 import shutil
@@ -44,31 +50,32 @@ def _deps_mtime():
     return max(os.path.getmtime(h) for h in hdrs)
 
 
-def build(verbose=True, force=False):
-    os.makedirs(OBJ, exist_ok=True)
+def build(verbose=True, force=False, lab=False):
+    obj_dir, lib_path = (OBJ + "_lab", LIB.replace(".so", "_lab.so")) if lab else (OBJ, LIB)
+    os.makedirs(obj_dir, exist_ok=True)
     cc = hipcc()
     hdr_m = _deps_mtime()
     objs, rebuilt = [], False
     for src in sources():
         sp = os.path.join(CSRC, src)
-        op = os.path.join(OBJ, src.rsplit(".", 1)[0] + ".o")
+        op = os.path.join(obj_dir, src.rsplit(".", 1)[0] + ".o")
         objs.append(op)
         if not force and os.path.exists(op) and os.path.getmtime(op) > max(os.path.getmtime(sp), hdr_m):
             continue
         cmd = [cc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-c", sp, "-o", op,
                "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-Wall", "-Wno-unused-function"]
-        cmd += EXTRA.get(src, EXTRA["default"])
+        cmd += EXTRA.get(src, EXTRA["default"]) + (["-DPE_LAB"] if lab else [])
         if verbose:
             print("[build]", " ".join(cmd), flush=True)
         subprocess.check_call(cmd)
         rebuilt = True
-    if rebuilt or force or not os.path.exists(LIB):
-        cmd = [cc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+    if rebuilt or force or not os.path.exists(lib_path):
+        cmd = [cc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib_path] + objs
         if verbose:
             print("[build]", " ".join(cmd), flush=True)
         subprocess.check_call(cmd)
-    return LIB
+    return lib_path
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    build(force="--force" in sys.argv, lab="--lab" in sys.argv)

@@ -24,7 +24,7 @@
 //     with 16 CONSECUTIVE output channels of one pixel; the epilogue turns that into whole 128-byte lines through a wave-private patch
 //     of the weight slot the tile has just finished with (all 160 KiB belong to the rings; one extra barrier per tile frees the slot).
 // Same products in the same K order with the same zero-initialised fp32 accumulators and bias added in the epilogue as
-// conv_igemm2_kernel: the results are bit-identical (tests/test_conv_gpu.py::test_conv1x1_ring_is_bit_identical), so which kernel takes
+// conv_igemm2_kernel: the results are bit-identical (tests/test_ops_gpu.py::test_conv1x1_ring_kernel_matches_torch_and_conv_igemm2_bit_for_bit), so which kernel takes
 // a launch never shows in a frame's result.
 #include <atomic>
 
@@ -57,9 +57,18 @@ struct RingArgs {
     int res_mode, resH, resW;
     unsigned res_bytes;
     unsigned in_bytes;           // stride 2 (shortcut convolutions): output pixel (n, oh, ow) reads input pixel (n, 2 oh, 2 ow) of [N, H, W, K]
-    int abl;       // measurement builds (results wrong): 1 = no pixel DMA, 2 = no weight DMA, 4 = no ds_read / MFMA, 8 = no stores,
-                   // 16 = pixel slabs fetched as if the input were K-chunk-major [K / 64][M][64] (contiguous 16 KiB per slab)
+#ifdef PE_LAB
+    int abl;       // LAB builds only (`python -m proben_amd.build --lab` -> libproben_hip_lab.so; results wrong): 1 = no pixel DMA, 2 = no weight DMA,
+                   // 4 = no ds_read / MFMA, 8 = no stores, 16 = pixel slabs fetched as if the input were K-chunk-major [K / 64][M][64]
+#endif
 };
+// The measurement switches of DESIGN 11.1's ablation budget exist in the lab library only: the product object contains no such branch
+// (tests/test_build_audit.py::test_product_library_has_no_measurement_switches).
+#ifdef PE_LAB
+#define RG_ABL(bits) ((a.abl & (bits)) != 0)
+#else
+#define RG_ABL(bits) false
+#endif
 
 __device__ __forceinline__ int4v rg_make_rsrc(const void* p, unsigned bytes) {
     const unsigned long long a = reinterpret_cast<unsigned long long>(p);
@@ -240,12 +249,12 @@ __global__ __launch_bounds__(RG_THREADS) void conv1x1_ring_kernel(RingArgs a) {
                 soff = u_mt < nmt ? (unsigned)(u_ks * 128) : 0u;
             }
             const unsigned lds = smem_base + stage * RG_ASTAGE_B;
-            if (a.abl & 16) {
+            if (RG_ABL(16)) {
                 soff = u_mt < nmt ? (unsigned)((u_ks * a.M + mrow0) * 128) : 0u;
 #pragma unroll
                 for (int q = 0; q < 16; ++q) vo[q] = (q * 8 + lrow < vrows) ? (unsigned)(q * 1024 + lane * 16) : RG_OOB;
             }
-            if (!(a.abl & 1)) {
+            if (!RG_ABL(1)) {
                 rg_dma8(lds, rs, soff, vo[0], vo[1], vo[2], vo[3], vo[4], vo[5], vo[6], vo[7]);
                 rg_dma8(lds + 8192, rs, soff, vo[8], vo[9], vo[10], vo[11], vo[12], vo[13], vo[14], vo[15]);
             }
@@ -280,9 +289,12 @@ __global__ __launch_bounds__(RG_THREADS) void conv1x1_ring_kernel(RingArgs a) {
         const int4v rs = rg_make_rsrc(a.wgt, (unsigned)a.Cout * (unsigned)a.K * 2u);
         int u_ks = 0, u_n = 0, u_mt = 0;
         auto issue = [&](int stage) {
-            const unsigned soff = u_mt < nmt ? (unsigned)((n0 + u_n) * RG_BN * a.K + u_ks * 64) * 2u : RG_OOB;
+            // The last two issues of a workgroup lie beyond its run (they only keep the vmcnt accounting uniform; nobody reads them): they
+            // re-fetch the run's FIRST slab.  Not an out-of-range soffset - the buffer range check covers the per-lane offset only, an
+            // SGPR offset of 2 GiB would be added to the base unchecked.
+            const unsigned soff = u_mt < nmt ? (unsigned)((n0 + u_n) * RG_BN * a.K + u_ks * 64) * 2u : (unsigned)(n0 * RG_BN * a.K) * 2u;
             const unsigned lds = smem_base + RG_BBASE + stage * RG_BSTAGE_B;
-            if (!(a.abl & 2)) {
+            if (!RG_ABL(2)) {
                 rg_dma8(lds, rs, soff, rel[0], rel[1], rel[2], rel[3], rel[4], rel[5], rel[6], rel[7]);
                 rg_dma8(lds + 8192, rs, soff, rel[8], rel[9], rel[10], rel[11], rel[12], rel[13], rel[14], rel[15]);
                 rg_dma8(lds + 16384, rs, soff, rel[16], rel[17], rel[18], rel[19], rel[20], rel[21], rel[22], rel[23]);
@@ -369,7 +381,7 @@ __global__ __launch_bounds__(RG_THREADS) void conv1x1_ring_kernel(RingArgs a) {
         // ONE code path: a wave that owns one block of a partial tile multiplies the loader's zeros for the other (a second, 1-block
         // path makes the accumulators PHI values: 32 v_mov per K-step behind the MFMAs - measured +9 us per launch); a wave that owns
         // none skips the step, which leaves its SIMD to the other wave: a partial tile costs about half a tile either way
-        if (mine >= 1 && !(a.abl & 4)) rg_compute<2>(acc, pa, pb, fswa, fswb, fkh);
+        if (mine >= 1 && !RG_ABL(4)) rg_compute<2>(acc, pa, pb, fswa, fswb, fkh);
         if (++ks == nk) {
             // ---- tile epilogue: + bias, ReLU, fp16, WHOLE 128-byte lines.  Stores straight from the accumulator layout are 16-byte
             // pieces 512 B apart - 64 write requests per instruction, measured at 17 of the launch's 78 us (profiles/r05_ring_abl.txt).
@@ -382,7 +394,7 @@ __global__ __launch_bounds__(RG_THREADS) void conv1x1_ring_kernel(RingArgs a) {
             const int mrow0 = (b0 + 4 * mt) * 32;
             int vrows = (nbt < 4 ? nbt : 4) * 32;
             vrows = vrows < a.M - mrow0 ? vrows : a.M - mrow0;
-            if (a.abl & 8) vrows = 0;
+            if (RG_ABL(8)) vrows = 0;
             const int chw = n * RG_BN + wn * 64;                    // this wave's first output channel
             rg_bias_wait(bs);
             const int rr = lane >> 3, rp = lane & 7;
@@ -432,7 +444,9 @@ __global__ __launch_bounds__(RG_THREADS) void conv1x1_ring_kernel(RingArgs a) {
 
 namespace pe {
 std::atomic<int> g_ring_wgs{256};
+#ifdef PE_LAB
 std::atomic<int> g_ring_abl{0};
+#endif
 
 // true when the ring kernel can take the launch (the caller has checked: 1x1, stride 1, no residual, fp16 output)
 bool conv1x1_ring_eligible(int M, int K, int Cout, int cout_store, int out_stride, long long in_pixels) {
@@ -451,7 +465,9 @@ int conv1x1_ring_launch(const void* in, const void* wgt, const float* bias, cons
     a.res_bytes = res_mode == 1 ? (unsigned)((long long)M * Cout * 2) : res_mode == 2 ? (unsigned)((long long)N * resH * resW * Cout * 2) : 0u;
     a.nblk = pe::ceil_div(M, 32);
     a.tiles_n = Cout / RG_BN;
+#ifdef PE_LAB
     a.abl = g_ring_abl.load(std::memory_order_relaxed);
+#endif
     const int wgs = g_ring_wgs.load(std::memory_order_relaxed);
     // Cout > 256: tiles_n workgroups per run when every run still has at least one m-tile's worth of blocks
     int grid = a.nblk < wgs ? a.nblk : wgs;
@@ -476,8 +492,10 @@ extern "C" int pe_test_set_ring_wgs(int wgs) {
     if (wgs >= 8 && wgs <= 1024) pe::g_ring_wgs = wgs;
     return PE_OK;
 }
-// ablation bits of the ring kernel (RingArgs::abl; results are WRONG for any non-zero value - scripts/r05_ring_abl.py only)
+#ifdef PE_LAB
+// ablation bits of the ring kernel (RingArgs::abl; results are WRONG for any non-zero value - scripts/archive/r05_ring_abl.py with the lab library only)
 extern "C" int pe_test_set_ring_ablation(int bits) {
     pe::g_ring_abl = bits;
     return PE_OK;
 }
+#endif

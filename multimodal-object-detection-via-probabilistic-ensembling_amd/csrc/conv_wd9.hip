@@ -51,14 +51,6 @@ int wd9_rpn_head(ConvWdArgs a, hipStream_t st) {
 
 }  // namespace pe
 
-extern "C" int pe_conv_wd_set_concurrent_streams(int32_t streams) {
-    // Kept for ABI stability (include/proben_hip.h): it sized round 4's opt-in persistent tail kernel.  The persistent kernels that ship
-    // (pure 3x3, RPN head, csrc/conv1x1_ring.hip) measured best at one workgroup per CU with one, two and three detector streams, so
-    // the hint is validated and otherwise ignored.
-    PE_CHECK_ARG(streams >= 1 && streams <= 8, "pe_conv_wd_set_concurrent_streams: streams must be in 1 .. 8 (got %d)", streams);
-    return PE_OK;
-}
-
 extern "C" int pe_test_set_wd9_wgs(int pure, int tail) {
     (void)tail;
     auto clamp = [](int n) { return n < 8 ? 8 : (n > 256 ? 256 : n / 8 * 8); };

@@ -27,8 +27,11 @@ int pe_test_wd9_head_takes(int N, int H, int W);
 int pe_test_set_wd9_wgs(int pure, int tail);
 /* workgroups of the persistent 1x1 ring kernel (default 256 = one per CU) */
 int pe_test_set_ring_wgs(int wgs);
-/* ablation builds of the ring kernel (csrc/conv1x1_ring.hip RingArgs::abl; non-zero = wrong results, timing only) */
+#ifdef PE_LAB
+/* LAB library only (`python -m proben_amd.build --lab`): ablation bits of the ring kernel (csrc/conv1x1_ring.hip RingArgs::abl; non-zero =
+ * wrong results, timing only).  The product library has neither the symbol nor the branches. */
 int pe_test_set_ring_ablation(int bits);
+#endif
 /* batched NMS: 1 (default) = input whose live rows are already in (class, score descending, row) order skips the sorting network
  * (the RPN's hand-over), 0 = the network always runs (same result; A/B and the identity test).  Synchronises the device. */
 int pe_test_set_nms_presorted(int on);

@@ -33,9 +33,14 @@ The protocol (`id_setup` 0 = "Reasonable", the one the reference asks for):
     operating point - kept) and averaged in log space (`MR = exp(mean(log(mr)))`; a 0 among them makes the result 0, as in the script);
   * `all` = every image, `day` = the first 1455 image ids in sorted order, `night` = the rest (the test-all-20 split: 2252 frames).
 
-One deliberate difference: the published script finds a kept detection's row of the overlap matrix by `id - id of the first kept
-detection`, which is the right row only while no higher-scoring detection of the image was dropped by the height filter and the file lists
-an image's rows by descending score; here the rows of the KEPT detections are used, which is what that arithmetic means to select.
+The published script's row arithmetic is REPRODUCED by default (reproduce the quirk, offer the switch): it computes the
+overlap matrix of an image over ALL its detections in descending score order, then drops the detections outside the expanded height
+range and looks a kept detection's row up as `id - id of the first kept detection` (ids = 1-based positions in the result file).  That is
+the detection's own row only while the file lists an image's rows by descending score and no higher-scoring detection of the image was
+dropped; otherwise a kept detection is matched with ANOTHER detection's overlaps (a negative difference wraps around like NumPy's
+indexing, a difference beyond the image's detections is an IndexError here as there).  `fix_row_index=True` (`KAISTParams.fixRowIndex`,
+`evaluate(..., fix_row_index=True)`, `demo_LAMR_KAIST --fix-row-index`) uses each kept detection's own row - what rounds 4-5 shipped as
+the only behaviour.  tests/test_kaist_eval_cpu.py::test_row_index_quirk_and_its_fix works a case by hand where the two differ.
 """
 import copy
 import json
@@ -58,6 +63,7 @@ class KAISTParams:
         self.SetupLbl = ["Reasonable", "Reasonable_small", "Reasonable_occ=heavy", "All"]
         self.bndRng = [5, 5, 635, 507]
         self.expFilter = 1.25
+        self.fixRowIndex = False      # False: the published `id - first kept id` row lookup; True: every kept detection's own row
 
 
 class KAIST:
@@ -171,25 +177,37 @@ class KAISTPedEval:
         return box[order], ig[order]
 
     def _dt_table(self, img_id, id_setup):
+        """Detections of an image in descending score order (stable, at most maxDets): (boxes, scores, ids) of ALL of them and the mask
+        of those inside the expanded height range."""
         p = self.params
         anns = self.cocoDt.anns(img_id, p.catIds)
         box = np.asarray([a["bbox"] for a in anns], dtype=np.float64).reshape(-1, 4)
         score = np.asarray([a["score"] for a in anns], dtype=np.float64)
         height = np.asarray([a["height"] for a in anns], dtype=np.float64)
+        ids = np.asarray([a["id"] for a in anns], dtype=np.int64)
         order = np.argsort(-score, kind="mergesort")[:p.maxDets[-1]]
-        box, score, height = box[order], score[order], height[order]
+        box, score, height, ids = box[order], score[order], height[order], ids[order]
         h0, h1 = p.HtRng[id_setup]
         keep = (height >= h0 / p.expFilter) & (height < h1 * p.expFilter)
-        return box[keep], score[keep]
+        return box, score, ids, keep
 
     def evaluateImg(self, img_id, id_setup):
         gbox, gig = self._gt_table(img_id, id_setup)
-        dbox, dscore = self._dt_table(img_id, id_setup)
-        if len(gbox) == 0 and len(dbox) == 0:
+        abox, ascore, aid, keep = self._dt_table(img_id, id_setup)
+        dbox, dscore = abox[keep], ascore[keep]
+        if len(gbox) == 0 and len(abox) == 0:
             return None
         p = self.params
+        if p.fixRowIndex or len(dbox) == 0:
+            ov = overlaps(dbox, gbox, gig)
+        else:
+            # the published lookup: row (id - id of the first kept detection) of the matrix over ALL detections in score order
+            rows = aid[keep] - aid[keep][0]
+            if rows.max() >= len(abox) or rows.min() < -len(abox):
+                raise IndexError(f"image {img_id}: the published row lookup `id - first kept id` = {int(rows.max())} leaves the image's "
+                                 f"{len(abox)} detections (the result file does not list the image's rows together); fix_row_index=True uses each detection's own row")
+            ov = overlaps(abox, gbox, gig)[rows]
         T, G, D = len(p.iouThrs), len(gbox), len(dbox)
-        ov = overlaps(dbox, gbox, gig)
         gtm = np.zeros((T, G), dtype=bool)
         dtm = np.zeros((T, D), dtype=bool)
         dt_ig = np.zeros((T, D), dtype=bool)
@@ -272,15 +290,17 @@ class KAISTPedEval:
 DAY_FRAMES = 1455      # test-all-20: image ids 0 .. 1454 are the day sets (set06-08), the rest the night sets (set09-11)
 
 
-def evaluate(test_annotation_file, user_submission_file, phase_codename="Multispectral", plot=False):
+def evaluate(test_annotation_file, user_submission_file, phase_codename="Multispectral", plot=False, fix_row_index=False):
     """The call of demo_LAMR_KAIST.py:145.  Returns {'all' | 'day' | 'night': KAISTPedEval (evaluated, accumulated)} and prints the
-    three "Reasonable" miss rates and the recall.  `plot` is accepted and ignored (no matplotlib dependency)."""
+    three "Reasonable" miss rates and the recall.  `plot` is accepted and ignored (no matplotlib dependency).  `fix_row_index` (an
+    addition, default off): see the module docstring."""
     gt = KAIST(test_annotation_file)
     dt = gt.loadRes(user_submission_file)
     img_ids = sorted(gt.getImgIds())
     method = os.path.basename(user_submission_file).split("_")[0] if isinstance(user_submission_file, str) else "unknown"
     base = KAISTPedEval(gt, dt, "bbox", method)
     base.params.catIds = [1]
+    base.params.fixRowIndex = bool(fix_row_index)
     result = {}
     for name, ids in (("all", img_ids), ("day", img_ids[:DAY_FRAMES]), ("night", img_ids[DAY_FRAMES:])):
         ev = copy.copy(base)

@@ -227,13 +227,6 @@ def conv2d_nhwc(x, weight, bias, *, kernel, stride=1, relu=False, residual=None,
     return out
 
 
-def set_concurrent_streams(n):
-    """Tell the library how many detectors run concurrently on their own HIP streams (pipeline.py).  Validated and, since round 5,
-    otherwise ignored: the persistent kernels that ship measured best at one workgroup per CU under 1, 2 and 3 streams (the hint sized
-    round 4's opt-in fused-tail kernel, which left the library).  Process-global; never changes results."""
-    _lib.check(_lib.lib().pe_conv_wd_set_concurrent_streams(int(n)), "pe_conv_wd_set_concurrent_streams")
-
-
 def conv_wd_supported(kernel, stride, H, W, Cin, Cout):
     """True when the weights-direct kernel (csrc/conv_wd.h) takes this geometry."""
     return bool(_lib.lib().pe_conv_wd_supported(int(kernel), int(stride), int(H), int(W), int(Cin), int(Cout)))

@@ -88,13 +88,7 @@ class FramePairPipeline:
     def __call__(self, frames_per_detector, out_sizes, resize_to):
         """frames_per_detector[d]: the batch for detector d ([B,H,W,C] uint8/float tensor or list of tensors).
         Returns (list of per-detector result dicts, fused dict of fusion.fuse_detections)."""
-        # a hint about the number of concurrent streams (it sized round 4's opt-in persistent tail kernel; the library validates and
-        # otherwise ignores it since round 5 - kept so that a future kernel that wants the information finds it here)
-        L.set_concurrent_streams(len(self.streams) if self.streams else 1)
-        try:
-            return self._run(frames_per_detector, out_sizes, resize_to)
-        finally:
-            L.set_concurrent_streams(1)
+        return self._run(frames_per_detector, out_sizes, resize_to)
 
     def _run(self, frames_per_detector, out_sizes, resize_to):
         if self.staggered:

@@ -175,3 +175,30 @@ def labelled_frames(n, height=512, width=640, seed=0, max_objects=6):
             classes.append(c)
         gts.append((np.asarray(boxes, dtype=np.float32).reshape(-1, 4), np.asarray(classes, dtype=np.int64)))
     return frames, gts
+
+
+def labelled_frames_rgb(n, height=512, width=640, seed=0, max_objects=6, hidden=0.2):
+    """The 'RGB camera' of the scenes `labelled_frames(n, seed=seed)` shows to the thermal one (fused-mAP harness,
+    tests/golden/gen_fused_map.py): the SAME objects (boxes and classes are `labelled_frames`' own), another appearance - tinted
+    noise background, class 0 red-ish, class 1 blue-ish, class 2 a yellow / navy checkerboard - and a fraction `hidden` of the
+    objects not drawn at all (what a night scene does to the RGB detector), so that the two detectors' lists differ the way
+    ProbEn's inputs do: common objects from both, some from one only.  Returns (frames [n,H,W,3] uint8 BGR order, the same ground truth)."""
+    _, gts = labelled_frames(n, height, width, seed, max_objects)
+    rng = np.random.default_rng(seed + 100003)
+    tint = np.array([95.0, 110.0, 120.0])
+    frames = (rng.normal(0.0, 35.0, size=(n, height, width, 3)) + tint).clip(0, 255).astype(np.uint8)
+    yy, xx = np.mgrid[0:height, 0:width]
+    checker = (((yy // 8) + (xx // 8)) % 2).astype(bool)
+    colours = {0: np.array([60.0, 90.0, 225.0]), 1: np.array([215.0, 120.0, 40.0])}
+    for i in range(n):
+        for b, c in zip(gts[i][0].astype(np.int64), gts[i][1]):
+            drawn = rng.random() >= hidden
+            noise = rng.normal(0.0, 8.0, size=(b[3] - b[1], b[2] - b[0], 3))
+            if not drawn:
+                continue
+            if int(c) == 2:
+                val = np.where(checker[b[1]:b[3], b[0]:b[2], None], np.array([40.0, 230.0, 230.0]), np.array([120.0, 20.0, 20.0])) + noise
+            else:
+                val = colours[int(c)] + noise
+            frames[i, b[1]:b[3], b[0]:b[2]] = val.clip(0, 255).astype(np.uint8)
+    return frames, gts

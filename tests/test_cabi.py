@@ -72,8 +72,6 @@ def test_argument_checks_answer_before_any_device_work(built_lib):
     assert L.pe_sgd_momentum_f32(None, None, None, None, 8, 0.1, 0.9, 0.0, 1.0, 1, None) != 0 and "null pointer" in err()
     assert L.pe_sgd_momentum_f32(4096 + 8, 4096, 4096, None, 8, 0.1, 0.9, 0.0, 1.0, 1, None) != 0 and "16-byte aligned" in err()
     assert L.pe_sgd_momentum_f32(4096, 4096, 4096, 4096 + 4, 8, 0.1, 0.9, 0.0, 1.0, 1, None) != 0 and "16-byte aligned" in err()
-    assert L.pe_conv_wd_set_concurrent_streams(0) != 0 and "streams" in err()
-    assert L.pe_conv_wd_set_concurrent_streams(2) == 0 and L.pe_conv_wd_set_concurrent_streams(1) == 0
     feats = (ctypes.c_void_p * 4)(4096, 4096, 4096, 4096)
     hw = (ctypes.c_int32 * 8)(200, 256, 100, 128, 50, 64, 25, 32)
     sc = (ctypes.c_float * 4)(0.25, 0.125, 0.0625, 0.03125)

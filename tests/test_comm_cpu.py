@@ -78,7 +78,7 @@ def _bench_step_worker(rank, world, port, tmp):
 
         def __call__(self, batch, out_sizes, resize_to):
             B, D = 3, 5
-            fused = {"boxes": torch.full((B, D, 4), float(rank)), "scores": torch.full((B, D), 0.5 + rank), "classes": torch.full((B, D), float(rank)),
+            fused = {"boxes": torch.full((B, D, 4), float(rank), dtype=torch.float64), "scores": torch.full((B, D), 0.5 + rank), "classes": torch.full((B, D), float(rank)),
                      "counts": torch.tensor([1 + rank, 2 + rank, 0], dtype=torch.int32)}
             return [fused], fused
     pipeline.FramePairPipeline = StubPipeline
@@ -87,11 +87,14 @@ def _bench_step_worker(rank, world, port, tmp):
     comm.all_gather_fused_rows = lambda payload: seen.append(orig(payload)) or seen[-1]
     frames = [torch.zeros((3, 8, 8, 3), dtype=torch.uint8)]
     step = bench.make_step([None], frames, {"fuse": ("probEn", "v-avg"), "detectors": [3]}, world)
+    calls = bench.count_collectives()       # counts at torch.distributed's entry points (what bench.py reports as collective_calls_per_step)
     for _ in range(2):
         step()
     assert len(seen) == 2
+    assert calls["n"] == 2, f"ONE collective per step is the documented contract (DESIGN 5), counted {calls['n']} in 2 steps"
     g = seen[-1]
-    assert g["boxes"].shape == (world, 3, 5, 4) and g["counts"].tolist() == [[1, 2, 0], [2, 3, 0]]
+    assert g["boxes"].shape == (world, 3, 5, 4) and g["boxes"].dtype == torch.float64 and g["counts"].tolist() == [[1, 2, 0], [2, 3, 0]]
+    assert g["boxes"][1].unique().tolist() == [1.0] and g["classes"].dtype == torch.float32 and g["counts"].dtype == torch.int32
     assert g["scores"][0].unique().tolist() == [0.5] and g["scores"][1].unique().tolist() == [1.5]     # rank order == GPU order
     if rank == 0:
         open(os.path.join(tmp, "ok_step"), "w").write("1")

@@ -131,6 +131,8 @@ def test_one_rank_rccl_group_runs_the_nccl_code_path(tmp_path):
     assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
     line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 1 and "all_gather_into_tensor" in line["config"]["collective"] and line["value"] > 0
+    assert line["config"]["collective_calls_per_step"] == 1, line["config"]      # ONE RCCL collective per step, counted inside the timed loop
+    assert len(line["value_windows"]) == 3 and all(v > 0 for v in line["value_windows"])
     # the box-head trainer: parameter broadcast + the bucketed gradient all-reduce over the one-rank RCCL group == the plain run
     logs = []
     for forced_run in (False, True):

@@ -121,6 +121,40 @@ def test_detection_height_filter_uses_the_expanded_range(tmp_path):
     np.testing.assert_allclose(ev.eval["xx"][0], [0.01])
 
 
+def test_row_index_quirk_and_its_fix(tmp_path):
+    """The published script looks a kept detection's overlaps up in row `id - id of the first kept detection` of the matrix over ALL of
+    the image's detections in score order.  One pedestrian (height 80), three detections of frame 1 in file order = score order:
+        id 1: score .9, 30 px tall -> dropped by the height filter (30 < 44), far from the pedestrian      matrix row 0: overlap 0
+        id 2: score .8, exactly on the pedestrian                                                         matrix row 1: overlap 1
+        id 3: score .7, 80 px tall, far away                                                              matrix row 2: overlap 0
+    Kept: ids 2, 3 -> rows 2 - 2 = 0 and 3 - 2 = 1: the detection ON the pedestrian is judged with the dropped detection's overlaps (a
+    false positive), the far one with the overlaps of the detection on the pedestrian (a true positive).  Default = the script's
+    arithmetic; fix_row_index=True = each detection's own row."""
+    gt = ann_file(tmp_path, 10, [(0, 100, 100, 40, 80)])
+    dt = det_file(tmp_path, [(1, 400, 300, 15, 30, 0.9), (1, 100, 100, 40, 80, 0.8), (1, 300, 300, 40, 80, 0.7)])
+    pub = evaluate(gt, dt, "Multispectral")["all"]
+    fix = evaluate(gt, dt, "Multispectral", fix_row_index=True)["all"]
+    assert pub.evalImgs[0]["dtScores"].tolist() == fix.evalImgs[0]["dtScores"].tolist() == [0.8, 0.7]
+    assert pub.evalImgs[0]["dtMatches"].tolist() == [[False, True]]
+    assert fix.evalImgs[0]["dtMatches"].tolist() == [[True, False]]
+    np.testing.assert_allclose(pub.eval["yy"][0], [1.0, 0.0])     # miss rate after the .8 (counted false) and after the .7
+    np.testing.assert_allclose(fix.eval["yy"][0], [0.0, 0.0])
+    np.testing.assert_allclose(pub.eval["xx"][0], [0.1, 0.1])     # FPPI (10 images): the false positive comes first ...
+    np.testing.assert_allclose(fix.eval["xx"][0], [0.0, 0.1])     # ... or last
+    # reference points below 0.1 FPPI: the published lookup finds no operating point (reads the last one: miss rate 0), the fix finds
+    # the true positive at FPPI 0 -> both 0 here; the curves above are where the two differ
+    # no height-filtered detection in front and score-ordered rows: the two agree (the usual case)
+    dt2 = det_file(tmp_path, [(1, 100, 100, 40, 80, 0.8), (1, 300, 300, 40, 80, 0.7), (1, 400, 300, 15, 30, 0.6)], name="KAIST_b_result.txt")
+    a, b = evaluate(gt, dt2)["all"], evaluate(gt, dt2, fix_row_index=True)["all"]
+    assert a.evalImgs[0]["dtMatches"].tolist() == b.evalImgs[0]["dtMatches"].tolist() == [[True, False]]
+    # an image whose rows are not listed together: the difference leaves the image's detections -> IndexError, as in the script
+    gt3 = ann_file(tmp_path, 10, [(0, 100, 100, 40, 80), (1, 100, 100, 40, 80)], name="KAIST_c_annotation.json")
+    dt3 = det_file(tmp_path, [(1, 100, 100, 40, 80, 0.9), (2, 100, 100, 40, 80, 0.8), (2, 300, 300, 40, 80, 0.7), (1, 300, 300, 40, 80, 0.6)], name="KAIST_c_result.txt")
+    with pytest.raises(IndexError, match="first kept id"):
+        evaluate(gt3, dt3)
+    assert evaluate(gt3, dt3, fix_row_index=True)["all"].evalImgs[0]["dtMatches"].tolist() == [[True, False]]
+
+
 def test_overlap_against_ignored_ground_truth_is_over_the_detection_area():
     """Real box: intersection / union.  Ignored box: intersection / detection area."""
     d = [[0, 0, 10, 10]]
