@@ -26,6 +26,13 @@ void set_error(const char* fmt, ...);
 
 namespace {
 
+// "a sorts before b" in `np.argsort(-score, kind="mergesort")` (cocoeval.py:177,257,371): descending scores, NaN LAST (NumPy orders NaN
+// behind every number; NaNs are equivalent to each other, so the stable sort keeps their file order).  A bare `a > b` is not a strict weak
+// ordering once a NaN is in the list - std::stable_sort then returns an arbitrary order, and a NaN score is what the reference's own
+// bayesian_fusion_multiclass makes of a detection whose class probabilities sum to 1 + 1 ulp (background = 1 - sum < 0, log -> NaN;
+// demo_probEn.py:32-42): 15 of 7 885 fused rows on the round-6 fused-mAP fixture moved the AP by 6 points before this rule.
+inline bool score_before(double a, double b) { return a > b || (a == a && b != b); }
+
 struct PairEval {                 // one (category, image) cell; empty() when it has neither GT nor detections
     int D = 0, G = 0;
     bool present = false;
@@ -88,7 +95,7 @@ void eval_pair(Ctx& c, int64_t cell) {
     pe.present = true;
     // detections: stable sort by -score, keep maxDets[-1]   (cocoeval.py:177-179, 257-258)
     std::vector<int64_t> dts(c.dt_idx.begin() + d0, c.dt_idx.begin() + d1);
-    std::stable_sort(dts.begin(), dts.end(), [&](int64_t a, int64_t b) { return c.dt_score[a] > c.dt_score[b]; });
+    std::stable_sort(dts.begin(), dts.end(), [&](int64_t a, int64_t b) { return score_before(c.dt_score[a], c.dt_score[b]); });
     const int cap = c.max_dets[c.M - 1];
     if ((int)dts.size() > cap) dts.resize(cap);
     const int D = (int)dts.size();
@@ -191,7 +198,7 @@ void accumulate_cell(const Ctx& c, int k, int a, int m, double* precision, doubl
         npig += pe.gt_kept[a];
     }
     if (!any || npig == 0) return;
-    std::stable_sort(rows.begin(), rows.end(), [](const Row& x, const Row& y) { return x.score > y.score; });
+    std::stable_sort(rows.begin(), rows.end(), [](const Row& x, const Row& y) { return score_before(x.score, y.score); });
     const int nd = (int)rows.size();
     const double eps = std::numeric_limits<double>::epsilon();  // np.spacing(1)
     std::vector<double> rc(nd), pr(nd);

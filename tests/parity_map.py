@@ -129,3 +129,209 @@ def measure(golden_dir):
         "box_offset_std_of_mean_px": {c: float(db[:, i].std() / max(len(db), 1) ** 0.5) for i, c in enumerate(["x1", "y1", "x2", "y2"])},
         "box_abs_max_coord_median_px": float(np.median(np.abs(db).max(1))) if len(db) else None}
     return rec
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# FUSED mAP (BASELINE's metric: the AP of the rows ProbEn makes of two detectors' lists).  demo/FLIR/demo_probEn.py:198-298 ->
+# detectron2/evaluation/FLIR_evaluation.py:249-310.  Fixtures: tests/golden/gen_fused_map.py (second pseudo-trained detector on the
+# RGB rendering of the same scenes + the oracle's rows of BOTH detectors with class probabilities and variances).
+# ------------------------------------------------------------------------------------------------------------------------
+FUSED_METHODS = (("probEn", "v-avg"), ("avg", "s-avg"))
+
+
+def load_fused_fixture(golden_dir):
+    """(state dicts (thermal, rgb), [(name, thermal frames, rgb frames, ground truth, oracle rows thermal, oracle rows rgb)])."""
+    import proben_amd  # noqa: F401
+    from proben_amd.synthetic import labelled_frames, labelled_frames_rgb, synthetic_state_dict
+    sds = []
+    for fn in ("pseudo_heads_r101.npz", "pseudo_heads_r101_rgb.npz"):
+        z = np.load(os.path.join(golden_dir, fn))
+        sd = synthetic_state_dict(int(z["depth"]), 3, 3, seed=int(z["seed"]))
+        for k in z.files:
+            if "/" in k:
+                sd[k.replace("/", ".")] = torch.from_numpy(z[k])
+        sds.append(sd)
+    e = np.load(os.path.join(golden_dir, "fused_map_sets.npz"))
+    n = int(e["n_frames"])
+    sets = []
+    for k in sorted(e.files):
+        if k.startswith("t_") and "r_" + k[2:] in e.files:
+            seed = int(k[2:])
+            ft, gts = labelled_frames(n, seed=seed)
+            fr, _ = labelled_frames_rgb(n, seed=seed)
+            sets.append((f"seed {seed}", ft, fr, gts, e[k], e["r_" + k[2:]]))
+    return sds, sets
+
+
+def _info(rows, f):
+    r = rows[rows[:, 0] == f]
+    return {"img_name": str(f), "bbox": r[:, 1:5].astype(np.float64), "score": r[:, 5].astype(np.float64), "class": r[:, 6].astype(np.int64),
+            "prob": r[:, 7:10].astype(np.float64), "vars": r[:, 10:11].astype(np.float64)}
+
+
+def oracle_fused_rows(rows_t, rows_r, n_frames, method):
+    """The reference's per-image driver on the oracle detectors' lists (oracle.proben.late_fusion_rows' case split: nobody fired ->
+    skipped, one fired -> passed through, both -> fusion; detector order thermal, RGB) -> rows (frame, x1, y1, x2, y2, score, class)
+    with the float32 containers of the reference's Instances."""
+    from oracle import proben as O
+    out = []
+    for f in range(n_frames):
+        live = [x for x in (_info(rows_t, f), _info(rows_r, f)) if len(x["score"])]
+        if not live:
+            continue
+        if len(live) == 1:
+            b, s, c = live[0]["bbox"], live[0]["score"].astype(np.float32), live[0]["class"].astype(np.float32)
+        else:
+            b, s, c = O.fusion(list(method), *live)
+        b = np.asarray(b, dtype=np.float64).astype(np.float32).reshape(-1, 4)
+        out += [[f, *b[j], s[j], c[j]] for j in range(len(s))]
+    return np.asarray(out, dtype=np.float32).reshape(-1, 7)
+
+
+def hip_fused_rows(models, frames_t, frames_r, method, batch=16, keep_inputs=False):
+    """The product route of configs[2]: FramePairPipeline (both detectors on their streams -> pe_proben_pack_detections ->
+    pe_proben_fuse_batch) -> the fused rows of every frame.  keep_inputs: also the two detectors' own rows (for the flip analysis)."""
+    from proben_amd.data import resize_shortest_edge_shape
+    from proben_amd.fusion import check_candidate_overflow
+    from proben_amd.pipeline import FramePairPipeline
+    new_hw = resize_shortest_edge_shape(512, 640, 800, 1333)
+    pipe = FramePairPipeline(models, method[0], method[1])
+    rows, det_rows = [], [[], []]
+    for b0 in range(0, len(frames_t), batch):
+        ft, fr = torch.from_numpy(frames_t[b0:b0 + batch]).cuda(), torch.from_numpy(frames_r[b0:b0 + batch]).cuda()
+        dets, fused = pipe([ft, fr], [(512, 640)] * len(ft), new_hw)
+        pipe.wait((dets, fused))
+        check_candidate_overflow(fused)
+        cnt, off = fused["counts"].cpu().tolist(), fused["offsets"].cpu().tolist()
+        bx, sc, cl = fused["boxes"].float().cpu().numpy(), fused["scores"].cpu().numpy(), fused["classes"].cpu().numpy()
+        for i, (c, o) in enumerate(zip(cnt, off)):
+            assert c >= 0, "a fused image ran out of rows"
+            rows += [[b0 + i, *bx[o + j], sc[o + j], cl[o + j]] for j in range(c)]
+        if keep_inputs:
+            for d, acc in zip(dets, det_rows):
+                dc = d["counts"].cpu().tolist()
+                for i, c in enumerate(dc):
+                    b_, s_, c_ = d["boxes"][i, :c].cpu().numpy(), d["scores"][i, :c].cpu().numpy(), d["classes"][i, :c].cpu().numpy()
+                    acc += [[b0 + i, *b_[j], s_[j], c_[j]] for j in range(c)]
+    rows = np.asarray(rows, dtype=np.float32).reshape(-1, 7)
+    if keep_inputs:
+        return rows, [np.asarray(a, dtype=np.float32).reshape(-1, 7) for a in det_rows]
+    return rows
+
+
+def _iou_to(r, q):
+    iw = (np.minimum(r[3], q[:, 3]) - np.maximum(r[1], q[:, 1])).clip(0)
+    ih = (np.minimum(r[4], q[:, 4]) - np.maximum(r[2], q[:, 2])).clip(0)
+    inter = iw * ih
+    return inter / ((r[3] - r[1]) * (r[4] - r[2]) + (q[:, 3] - q[:, 1]) * (q[:, 4] - q[:, 2]) - inter + 1e-9)
+
+
+def _unmatched(a, b, n_frames, iou_min=0.9):
+    out = []
+    for f in range(n_frames):
+        ia, ib = np.nonzero(a[:, 0] == f)[0], np.nonzero(b[:, 0] == f)[0]
+        used = np.zeros(len(ib), bool)
+        for i in ia:
+            cand = np.nonzero((~used) & (b[ib, 6] == a[i, 6]))[0]
+            if len(cand):
+                iou = _iou_to(a[i], b[ib[cand]])
+                j = int(iou.argmax())
+                if iou[j] >= iou_min:
+                    used[cand[j]] = True
+                    continue
+            out.append(i)
+    return np.asarray(out, dtype=np.int64)
+
+
+def classify_fused(rows, idx, other, own_inputs_only):
+    """rows[idx]: one route's fused rows without a same-class IoU >= 0.9 partner among the other route's fused rows.  First match wins:
+      class_flip         the other route has a fused row at IoU >= 0.9 with another class
+      inherited          one of THIS route's own detector-level detections that the other route's detectors do not have (same class, IoU >=
+                         0.9) overlaps the row at IoU >= 0.5: the difference was there before ProbEn (a detector's final-NMS winner flip,
+                         threshold flip or missing proposal - profiles/r05_map_flips.json - handed through or averaged in)
+      fusion_level       the detectors' lists agree around the row, the other route has a same-class fused row at 0.5 <= IoU < 0.9: a
+                         cluster-membership decision (IoU against 0.5, score order) went the other way, or the averaged box moved
+      unexplained        nothing of the above"""
+    cls = {}
+    for i in idx:
+        r = rows[i]
+        o = other[other[:, 0] == r[0]]
+        iou = _iou_to(r, o) if len(o) else np.zeros(0)
+        same = o[:, 6] == r[6] if len(o) else np.zeros(0, bool)
+        mine = own_inputs_only[(own_inputs_only[:, 0] == r[0]) & (own_inputs_only[:, 6] == r[6])]
+        if len(o) and (iou[~same] >= 0.9).any():
+            c = "class_flip"
+        elif len(mine) and (_iou_to(r, mine) >= 0.5).any():
+            c = "inherited"
+        elif len(o) and ((iou >= 0.5) & (iou < 0.9) & same).any():
+            c = "fusion_level"
+        else:
+            c = "unexplained"
+        cls[int(i)] = c
+    return cls
+
+
+def measure_fused(golden_dir, methods=FUSED_METHODS, flips=True):
+    """Per method and evaluation set: AP table of oracle-detectors -> oracle.proben (the reference's route) and of HIP detectors ->
+    pe_proben_fuse_batch (the product's route) against the same ground truth; deltas, mean, standard error; the flip classes of the
+    fused rows (and, for scale, the same deltas of the two detectors alone on these sets)."""
+    from proben_amd.rcnn import DetectorConfig, GeneralizedRCNN
+    sds, sets = load_fused_fixture(golden_dir)
+    models = [GeneralizedRCNN(DetectorConfig(), sd) for sd in sds]
+    rec = {"models": "two R101-FPN, seeded random backbones (seeds 1 / 2), RPN + box predictor fitted on the thermal / RGB rendering of the same "
+                     "scenes (tests/golden/gen_pseudo_heads.py, gen_fused_map.py; 20 % of the objects invisible to the RGB detector)",
+           "north_star_tolerance_points": NORTH_STAR_POINTS, "methods": {}}
+    for method in methods:
+        mrec = {"sets": {}}
+        deltas, totals = [], {"oracle_only": {}, "hip_only": {}}
+        pool_gt, pool_o, pool_h, off = [], [], [], 0
+        for name, ft, fr, gts, ot, orr in sets:
+            n = len(ft)
+            ora = oracle_fused_rows(ot, orr, n, method)
+            hip, (ht, hr) = hip_fused_rows(models, ft, fr, method, keep_inputs=True)
+            so, sh = coco_stats(gts, ora), coco_stats(gts, hip)
+            deltas.append((sh - so)[:6] * 100)
+            ds, db, un_o, un_h = match_signed(ora, hip, n)
+            srec = {"frames": n, "ground_truth_objects": int(sum(len(g[0]) for g in gts)), "oracle_fused_rows": int(len(ora)), "hip_fused_rows": int(len(hip)),
+                    "oracle": {k: float(so[i] * 100) for i, k in enumerate(NAMES)}, "hip": {k: float(sh[i] * 100) for i, k in enumerate(NAMES)},
+                    "delta": {k: float(deltas[-1][i]) for i, k in enumerate(NAMES)}, "matched_pairs": int(len(ds)), "oracle_only": un_o, "hip_only": un_h,
+                    "matched_score_diff_sigma": float(ds.std()) if len(ds) else None,
+                    "matched_box_abs_max_coord_median_px": float(np.median(np.abs(db).max(1))) if len(db) else None}
+            if method == methods[0]:      # the detectors alone on the same frames (method-independent)
+                for tag, o_, h_ in (("thermal", ot[:, :7], ht), ("rgb", orr[:, :7], hr)):
+                    a, b = coco_stats(gts, o_), coco_stats(gts, h_)
+                    srec["detector_" + tag] = {"oracle": {k: float(a[i] * 100) for i, k in enumerate(NAMES[:3])},
+                                               "delta": {k: float((b[i] - a[i]) * 100) for i, k in enumerate(NAMES[:3])}}
+            if flips:
+                # detector-level rows only one side has (same class, IoU >= 0.9), both detectors together
+                o_in, h_in = np.concatenate([ot[:, :7], orr[:, :7]]), np.concatenate([ht, hr])
+                o_in_only = np.concatenate([ot[_unmatched(ot[:, :7], ht, n), :7], orr[_unmatched(orr[:, :7], hr, n), :7]])
+                h_in_only = np.concatenate([ht[_unmatched(ht, ot[:, :7], n)], hr[_unmatched(hr, orr[:, :7], n)]])
+                co = classify_fused(ora, _unmatched(ora, hip, n), hip, o_in_only)
+                ch = classify_fused(hip, _unmatched(hip, ora, n), ora, h_in_only)
+                for key, cl in (("oracle_only", co), ("hip_only", ch)):
+                    cnt = {}
+                    for c in cl.values():
+                        cnt[c] = cnt.get(c, 0) + 1
+                        totals[key][c] = totals[key].get(c, 0) + 1
+                    srec["flip_classes_" + key] = cnt
+                srec["detector_level_unmatched"] = {"oracle_only": int(len(o_in_only)), "hip_only": int(len(h_in_only)), "oracle_detections": int(len(o_in)),
+                                                    "hip_detections": int(len(h_in))}
+            mrec["sets"][name] = srec
+            pool_gt += list(gts)
+            for rows, pool in ((ora, pool_o), (hip, pool_h)):
+                r = rows.copy()
+                r[:, 0] += off
+                pool.append(r)
+            off += n
+        d = np.asarray(deltas)
+        mrec["n_sets"] = int(len(d))
+        mrec["delta_mean"] = {k: float(d[:, i].mean()) for i, k in enumerate(NAMES)}
+        mrec["delta_std"] = {k: float(d[:, i].std(ddof=1)) if len(d) > 1 else None for i, k in enumerate(NAMES)}
+        mrec["delta_standard_error"] = {k: float(d[:, i].std(ddof=1) / len(d) ** 0.5) if len(d) > 1 else None for i, k in enumerate(NAMES)}
+        po, ph = coco_stats(pool_gt, np.concatenate(pool_o)), coco_stats(pool_gt, np.concatenate(pool_h))
+        mrec["pooled"] = {"frames": off, "oracle": {k: float(po[i] * 100) for i, k in enumerate(NAMES)}, "delta": {k: float((ph[i] - po[i]) * 100) for i, k in enumerate(NAMES)}}
+        if flips:
+            mrec["flip_class_totals"] = totals
+        rec["methods"]["/".join(method)] = mrec
+    return rec

@@ -74,6 +74,32 @@ def test_native_cocoeval_bit_identical_to_numpy(n_images, seed, crowd, threads):
     assert np.array_equal(a.stats, b.stats)
 
 
+def test_native_cocoeval_orders_nan_scores_last_like_numpy():
+    """A NaN score is what the reference's own bayesian_fusion_multiclass (demo_probEn.py:32-42) makes of a cluster member whose class
+    probabilities sum to 1 + 1 ulp (background = 1 - sum < 0 -> log = NaN).  cocoeval.py sorts with np.argsort(-score, mergesort): NaN
+    last, stable.  The native evaluator used a bare `a > b` until round 6 - not an ordering once a NaN is in the list; the fused-mAP
+    fixture found it (15 NaN rows of 7 885 moved AP by 6 points).  NaN rows sprinkled over every cell: tables equal bit for bit, and the
+    same tables as with the NaN rows moved to the END of the file (they sort last wherever they stand)."""
+    gt, res = _random_eval_case(60, 5, True)
+    rng = np.random.default_rng(3)
+    nan_rows = [dict(r, score=float("nan")) for r in rng.choice(res, 25, replace=False)]
+    mixed = list(res)
+    for r in nan_rows:
+        mixed.insert(int(rng.integers(0, len(mixed))), r)
+    out = []
+    for rows in (mixed, res + nan_rows):
+        a = evaluation.COCOevalBBox(gt, rows, impl="numpy")
+        b = evaluation.COCOevalBBox(gt, rows, impl="native", num_threads=2)
+        for e in (a, b):
+            e.evaluate()
+            e.accumulate()
+            e.summarize(printer=None)
+        assert np.array_equal(a.eval["precision"], b.eval["precision"]) and np.array_equal(a.eval["recall"], b.eval["recall"])
+        assert np.array_equal(a.stats, b.stats)
+        out.append(b.stats)
+    assert np.array_equal(out[0], out[1])
+
+
 def test_native_cocoeval_empty_and_bad_rows():
     gt = {"images": [{"id": 1}], "annotations": [], "categories": [{"id": 1}]}
     e = evaluation.COCOevalBBox(gt, [])
