@@ -456,16 +456,16 @@ extern "C" int pe_nms_batched(const float* boxes, const float* scores, const int
     a.seg_start = (int32_t*)carve((size_t)B * n_max * 4);
     a.out_keep = out_keep; a.out_counts = out_counts;
     const size_t lds = (size_t)a.n_pad * 8;
-    PE_ENSURE_LDS(nms_sort_kernel, lds + 256, "pe_nms_batched(sort)");   // + the kernel's static LDS
+    PE_ENSURE_LDS(nms_sort_kernel, lds + 512, "pe_nms_batched(sort)");   // + the kernel's static LDS (~332 B of reduction / segment scratch)
     hipLaunchKernelGGL(nms_sort_kernel, dim3(B), dim3(kSortThreads), lds, st, a);
     PE_CHECK_LAUNCH("pe_nms_batched(sort)");
     hipLaunchKernelGGL(nms_mask_kernel, dim3(a.words, a.words, B), dim3(64), 0, st, a);
     PE_CHECK_LAUNCH("pe_nms_batched(mask)");
     const size_t lists = (((((size_t)n_max * 2 + 15) & ~(size_t)15) + (size_t)a.n_pad / 8 + 15) & ~(size_t)15);   // kept lists + flags
     size_t lds2 = std::max((size_t)a.n_pad * 8, lists + 16);
-    a.merge = lists + (size_t)n_max * 8 + 256 <= 160 * 1024;       // + the survivors' keys (at most one per row)
+    a.merge = lists + (size_t)n_max * 8 + 512 <= 160 * 1024;       // + the survivors' keys (at most one per row)
     if (a.merge) lds2 = std::max(lds2, lists + (size_t)n_max * 8);
-    PE_ENSURE_LDS(nms_scan_order_kernel, lds2 + 256, "pe_nms_batched(scan + order)");   // + the kernel's static LDS
+    PE_ENSURE_LDS(nms_scan_order_kernel, lds2 + 512, "pe_nms_batched(scan + order)");   // + the kernel's static LDS (~132 B)
     hipLaunchKernelGGL(nms_scan_order_kernel, dim3(B), dim3(kScanThreads), lds2, st, a);
     PE_CHECK_LAUNCH("pe_nms_batched(scan + order)");
     return PE_OK;

@@ -450,10 +450,15 @@ extern "C" int pe_proben_fuse_batch(const double* boxes, const double* scores, c
     const int L = score_mode == PE_SCORE_PROBEN ? num_classes + 1 : (score_mode == PE_SCORE_PROBEN_BINARY ? 2 : 0);
     const size_t lds_seq = (size_t)R * (8 * (6 + L + 5) + 4 + 4 + 4 * 2 + 1) + 16;
     const size_t lds_bits = lds_seq + (size_t)R * ((R + 63) / 64) * 16;        // + the two bit matrices
-    const bool bits = lds_bits <= 160 * 1024;
+    constexpr size_t kStatic = 512;                                            // the kernels' static __shared__ scratch (ncl_s, reductions)
+    const bool bits = lds_bits + kStatic <= 160 * 1024;
     const size_t lds = bits ? lds_bits : lds_seq;
-    if (lds > 160 * 1024) {
-        pe::set_error("pe_proben_fuse_batch: %zu bytes of LDS needed (> 160 KiB); lower max_rows_per_image", lds);
+    if (lds + kStatic > 160 * 1024) {
+        // a whole image's rows live in LDS (boxes, 1 / variance, class ids, log-odds, cluster tables: 8 (11 + L) + 17 bytes per row);
+        // capacity at K = 3: 1 195 rows per image (probEn), 1 400 (other score modes) - a detector contributes at most 100
+        pe::set_error("pe_proben_fuse_batch: %zu bytes of LDS needed (> 160 KiB): max_rows_per_image %d is above the per-image capacity of %zu rows "
+                      "for this score mode / class count", lds + kStatic, max_rows_per_image,
+                      (size_t)(160 * 1024 - kStatic - 16) / (size_t)(8 * (6 + L + 5) + 4 + 4 + 4 * 2 + 1));
         return PE_ERR_UNSUPPORTED;
     }
     ProbenArgs a{boxes, scores, probs, variances, classes, offsets, row_counts, passthrough, num_images, num_classes, R,

@@ -145,6 +145,12 @@ __device__ inline void fma_mix8(const uint4v& h, float w, float* acc) {
         acc[2 * d + 1] = fma_mix_hi(h[d], w, acc[2 * d + 1]);
     }
 }
+// lane l takes `yes` when bit l of the wave-uniform mask is set, else `no`: one VALU instruction with the mask in an SGPR pair
+__device__ inline unsigned lane_select(unsigned long long mask, unsigned no, unsigned yes) {
+    unsigned r;
+    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(no), "v"(yes), "s"(mask));
+    return r;
+}
 std::atomic<int> g_roi_fast{1};   // test hook: 0 = the per-lane form for every launch (A/B and the bit-identity test)
 
 // FAST (fp16, C == 256, pooled <= 8 x 8, one pooled row per pass): the wave-uniform form of the separable loop.  A wave owns two
@@ -157,7 +163,14 @@ std::atomic<int> g_roi_fast{1};   // test hook: 0 = the per-lane form for every 
 // one 199 M = 65 % of 0.57 ms, profiles/r05_roi_fast_ab.txt; 4 loads in flight per wave: 3, 6, 8 and 8 waves per SIMD are all
 // within 5 %).  A bin's own pixels are accumulated in the
 // same row-major order with the same weights; the padding adds w = 0 terms, which leave an accumulator that started at +0 as it is
-// -> the bits of the per-lane form (tests/test_ops_gpu.py::test_roi_align_fast_form_is_bit_identical).
+// -> the bits of the per-lane form (tests/test_ops_gpu.py::test_roi_align_fast_form_is_bit_identical).  Round 6: a padded
+// column is not LOADED either - the half-wave whose own window has ended gets an out-of-range per-lane offset (zeros from the bounds
+// check), selected by a wave-uniform lane mask in one VALU instruction - so a non-finite pixel next to a bin (0 x Inf = NaN) cannot
+// reach a bin that the per-lane form and the reference leave finite, and nothing rests on what lies behind the level's last pixel.
+// What remains of the kind (both table forms, finite features unaffected): a bin's table is a DENSE window from its first to its last
+// tap; with the adaptive sampling ratio (the detector's: POOLER_SAMPLING_RATIO 0, ceil(bin size) samples) every pixel of the window is
+// sampled, with a FIXED ratio and bins wider than `ratio` pixels the pixels between two samples sit in the window at weight zero - a
+// non-finite value there makes the bin NaN where the reference, which never reads it, stays finite.
 template <typename T, bool SEP, bool FAST>
 __global__ __launch_bounds__(256) void roi_align_kernel(RoiArgs a) {
     constexpr int V = Vec<T>::N;
@@ -226,6 +239,11 @@ __global__ __launch_bounds__(256) void roi_align_kernel(RoiArgs a) {
             const float* wxr = tabs.w[1][pw];
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(feat), 0, H * W * a.C * 2, 0x00020000);
             const unsigned voff = (unsigned)(tabs.first[1][pw] * a.C + cv * 8) * 2u;
+            const unsigned voob = 0xFFFFFFF0u;
+            const int nxa = __builtin_amdgcn_readfirstlane(tabs.n[1][pwa]), nxb = __builtin_amdgcn_readfirstlane(tabs.n[1][pwb]);
+            auto own = [&](int c) {      // lanes 0-31 (bin pwa) / 32-63 (bin pwb): the column is inside the lane's own window
+                return (c < nxa ? 0x00000000FFFFFFFFull : 0ull) | (c < nxb ? 0xFFFFFFFF00000000ull : 0ull);
+            };
             const unsigned step_c = (unsigned)a.C * 2u, step_r = (unsigned)(W - nxm + 1) * a.C * 2u;
             // x / count, correctly rounded, in 3 instead of ~10 instructions: with y = RN(1 / count), q = RN(x * y) is refined once
             // through the exact residual (Markstein).  Checked exhaustively against IEEE division over all 2^23 significands for every
@@ -250,7 +268,7 @@ __global__ __launch_bounds__(256) void roi_align_kernel(RoiArgs a) {
 #pragma unroll
                     for (int u = 0; u < MLP; ++u) {
                         w[u] = wyr[rr] * wxr[c];
-                        h[u] = __builtin_bit_cast(uint4v, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
+                        h[u] = __builtin_bit_cast(uint4v, __builtin_amdgcn_raw_buffer_load_b128(rs, lane_select(own(c), voob, voff), soff, 0));
                         const bool wrap = c + 1 == nxm;
                         soff += wrap ? step_r : step_c;
                         c = wrap ? 0 : c + 1;
@@ -267,7 +285,7 @@ __global__ __launch_bounds__(256) void roi_align_kernel(RoiArgs a) {
                     for (int u = 0; u < MLP - 1; ++u)
                         if (u < rem) {
                             w[u] = wyr[rr] * wxr[c];
-                            h[u] = __builtin_bit_cast(uint4v, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
+                            h[u] = __builtin_bit_cast(uint4v, __builtin_amdgcn_raw_buffer_load_b128(rs, lane_select(own(c), voob, voff), soff, 0));
                             const bool wrap = c + 1 == nxm;
                             soff += wrap ? step_r : step_c;
                             c = wrap ? 0 : c + 1;
@@ -281,7 +299,8 @@ __global__ __launch_bounds__(256) void roi_align_kernel(RoiArgs a) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         const float q = acc[e] * rcp;
-                        acc[e] = __builtin_fmaf(__builtin_fmaf(-count, q, acc[e]), rcp, q);
+                        const float rq = __builtin_fmaf(__builtin_fmaf(-count, q, acc[e]), rcp, q);
+                        acc[e] = __builtin_isinf(q) ? q : rq;      // an infinite sum stays infinite as under IEEE division (the residual of Inf is Inf - Inf)
                     }
                 } else {
 #pragma unroll
@@ -317,6 +336,7 @@ __global__ __launch_bounds__(256) void roi_align_kernel(RoiArgs a) {
                     const float wv = wyr[rr] * wxr[c];      // (rr, c) is always a valid table slot: read, then mask
                     w[u] = ok ? wv : 0.f;
                     h[u] = *reinterpret_cast<const half8*>(base + poff);
+                    if (!ok) h[u] = half8{0, 0, 0, 0, 0, 0, 0, 0};      // a padding slot re-reads the window's last pixel: 0 x Inf would turn an Inf bin into NaN (round 6)
                     const bool adv = i + u + 1 < npx;       // stays on the last pixel past the end; selects, no branches
                     const bool wrap = adv && c + 1 == nx;
                     poff += wrap ? step_r : (adv ? step_c : 0);

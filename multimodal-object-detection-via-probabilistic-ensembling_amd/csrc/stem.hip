@@ -5,14 +5,16 @@
 // it back; fused, a persistent block turns a 23 x 72 pixel input patch (NHWC4 fp16, 13 KB) into a 4 x 16 x 64
 // pooled tile entirely through LDS: HBM sees the 4-channel image once and the pooled map once.
 //
-// One block (4 waves) per pooled tile of PH x PW = 4 x 16:
-//   conv region  : rows 2*ph0-1 .. 2*ph0+7 (9), cols 2*pw0-1 .. 2*pw0+31 (33)  -> 297 conv pixels
-//   input patch  : rows 4*ph0-5 .. +22 (23), cols 4*pw0-6 .. +71 (72); out-of-image pixels are zero (conv padding)
+// One block (4 waves) per pooled tile of PH x PW = 5 x 16 (round 6; 4 x 16 before):
+//   conv region  : rows 2*ph0-1 .. 2*ph0+9 (11), cols 2*pw0-1 .. 2*pw0+31 (33)  -> 363 conv pixels = 12 MFMA pixel tiles of 32,
+//                  THREE per wave (4 x 16 gave 297 pixels = 10 tiles: 3 / 3 / 2 / 2 - the block waited for its two slow waves with half
+//                  the matrix pipes idle, and computed 1.16 conv pixels per useful one where this tile computes 1.13)
+//   input patch  : rows 4*ph0-5 .. +26 (27), cols 4*pw0-6 .. +71 (72); out-of-image pixels are zero (conv padding)
 //   GEMM         : D[cout 64][pixel 32] per MFMA pair; K = 7 rows x (8 taps x 4 channels) = 14 steps of 16.
 //                  The 8th tap is a zero weight in FRONT (tap t reads input column 2*c - 4 + t), which makes
 //                  every fragment a 16-byte aligned pair of NHWC4 pixels: ds_read_b128, no shuffles.
 //   weights      : A operand, 14 x 2 fragments held in registers for the block's whole life (persistent grid).
-//   epilogue     : bias + ReLU -> fp16 -> LDS [297][72]; conv pixels outside the conv map become 0, which equals
+//   epilogue     : bias + ReLU -> fp16 -> LDS [363][72]; conv pixels outside the conv map become 0, which equals
 //                  the pool's -inf padding because every window holds at least one real, non-negative value.
 //   pool         : 3x3/2 max over the LDS tile, 16-byte stores of 8 channels.
 #include <hip/hip_fp16.h>
@@ -24,17 +26,22 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float float16v __attribute__((ext_vector_type(16)));
 
-constexpr int PH = 4, PW = 16;                       // pooled tile
-constexpr int CR = 2 * PH + 1, CC = 2 * PW + 1;      // conv region 9 x 33
-constexpr int NPIX = CR * CC;                        // 297
-constexpr int PTILES = (NPIX + 31) / 32;             // 10 MFMA pixel tiles
-constexpr int IR = 2 * CR + 5, IC = 2 * CC + 6;      // input patch 23 x 72 pixels of 8 bytes
-constexpr int CHUNKS = IR * IC / 2;                  // 16-byte chunks (pixel pairs): 828
+constexpr int PH = 5, PW = 16;                       // pooled tile
+constexpr int CR = 2 * PH + 1, CC = 2 * PW + 1;      // conv region 11 x 33
+constexpr int NPIX = CR * CC;                        // 363
+constexpr int PTILES = (NPIX + 31) / 32;             // 12 MFMA pixel tiles: three per wave
+constexpr int IR = 2 * CR + 5, IC = 2 * CC + 6;      // input patch 27 x 72 pixels of 8 bytes
+constexpr int CHUNKS = IR * IC / 2;                  // 16-byte chunks (pixel pairs): 972
 constexpr int OPITCH = 72;                           // halves per conv pixel in LDS (64 + pad, 16-byte multiple)
 constexpr int THREADS = 256;
 constexpr int LOADS = (CHUNKS + THREADS - 1) / THREADS;  // 4
 constexpr int KSTEPS = 14;
 constexpr int WROW = 7 * 8 * 4;                      // 224 halves of weights per output channel
+constexpr int PATCH_HALFS = IR * IC * 4, COUT_HALFS = NPIX * OPITCH;
+constexpr int LDS_BYTES = (PATCH_HALFS + COUT_HALFS) * 2;   // 15 552 + 52 272 = 67 824: two blocks per CU
+constexpr int POOL_ITEMS = PH * PW * 8;              // 8-channel groups of the pooled tile
+static_assert(PTILES % 4 == 0, "the pixel tiles divide evenly over the four waves");
+static_assert(PATCH_HALFS % 8 == 0, "the conv tile starts 16-byte aligned behind the patch");
 
 struct StemArgs {
     const _Float16* x;     // [N, H, W, 4]
@@ -73,8 +80,9 @@ __device__ __forceinline__ void load_patch(const StemArgs& a, const Tile& t, hal
 }
 
 __global__ __launch_bounds__(THREADS, 2) void stem7x7_pool_kernel(StemArgs a) {
-    __shared__ __attribute__((aligned(16))) _Float16 patch[IR * IC * 4];
-    __shared__ __attribute__((aligned(16))) _Float16 cout_lds[NPIX * OPITCH];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    _Float16* patch = reinterpret_cast<_Float16*>(smem);
+    _Float16* cout_lds = patch + PATCH_HALFS;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l31 = lane & 31, khalf = lane >> 5;
 
@@ -147,8 +155,9 @@ __global__ __launch_bounds__(THREADS, 2) void stem7x7_pool_kernel(StemArgs a) {
         __syncthreads();
         // ---- pool 3x3 / 2 over the conv tile, 8 channels per item
 #pragma unroll
-        for (int it = 0; it < PH * PW * 8 / THREADS; ++it) {
+        for (int it = 0; it < (POOL_ITEMS + THREADS - 1) / THREADS; ++it) {
             const int item = threadIdx.x + it * THREADS;
+            if (item >= POOL_ITEMS) break;
             const int g = item & 7, pp = item >> 3;
             const int pr = pp / PW, pcol = pp % PW;
             const _Float16* src = cout_lds + ((2 * pr) * CC + 2 * pcol) * OPITCH + g * 8;
@@ -185,7 +194,8 @@ extern "C" int pe_stem_conv7x7_maxpool_f16(const void* x, const void* w_packed, 
     PE_CHECK_ARG(total < (1ll << 31), "pe_stem_conv7x7_maxpool_f16: too many tiles");
     a.total_tiles = (int)total;
     const int grid = (int)std::min<long long>(total, 256 * 2);
-    hipLaunchKernelGGL(stem7x7_pool_kernel, dim3(grid), dim3(THREADS), 0, (hipStream_t)stream, a);
+    PE_ENSURE_LDS(stem7x7_pool_kernel, (size_t)LDS_BYTES, "pe_stem_conv7x7_maxpool_f16");
+    hipLaunchKernelGGL(stem7x7_pool_kernel, dim3(grid), dim3(THREADS), (size_t)LDS_BYTES, (hipStream_t)stream, a);
     PE_CHECK_LAUNCH("pe_stem_conv7x7_maxpool_f16");
     return PE_OK;
 }

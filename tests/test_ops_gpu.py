@@ -828,19 +828,40 @@ def test_roi_align_sorted_order_moves_no_result(L, N, P):
         assert float(a.view(N, P, -1)[1, counts[1]:].abs().sum()) == 0
 
 
-@pytest.mark.parametrize("pooled,ratio,aligned,tiny", [((7, 7), 0, True, False), ((7, 7), 0, True, True), ((8, 8), 0, False, False), ((3, 5), 2, True, False), ((7, 7), 3, False, False)])
+@pytest.mark.parametrize("pooled,ratio,aligned,tiny", [((7, 7), 0, True, False), ((7, 7), 0, True, True), ((8, 8), 0, False, False), ((3, 5), 2, True, False), ((7, 7), 3, False, False),
+                                                       ((7, 7), 0, True, "nonfinite"), ((8, 8), 0, False, "nonfinite")])
 def test_roi_align_fast_form_is_bit_identical(L, pooled, ratio, aligned, tiny):
     """The wave-uniform form (fp16, C = 256: two bins per wave walk the wider of their two windows, scalar pixel walk, v_fma_mix,
     three-instruction exact division) against the per-lane form it replaces in the detector: the same bits.  Boxes cover every
     level, sub-pixel and whole-image sizes, boxes partly and wholly outside the image (empty windows next to live ones), the last
     image's bottom-right corner (padded columns run past the level's end: bounded buffer loads) and - single level, stride 4 - bins
-    above the table size (tap-form fallback inside the fast kernel); `tiny` scales the features into fp16 subnormals."""
+    above the table size (tap-form fallback inside the fast kernel); `tiny` scales the features into fp16 subnormals; "nonfinite"
+    (round 6) sprinkles +-Inf and NaN pixels over every level, the last pixel of the last image included: a bin next to such
+    a pixel stays finite in the per-lane form and in the reference (it never samples it), and so it must in the wave-uniform form - the
+    padded columns of the narrower bin are not loaded - while a bin that does sample it carries the same non-finite bits.  (Adaptive
+    sampling ratio only - the detector's: with a FIXED ratio whose samples lie more than a pixel apart the table's window holds
+    unsampled pixels at weight zero, and a non-finite one among them poisons the bin in both table forms; csrc/roi_align.hip says so.)"""
     from proben_amd import _lib
     H = _lib.test_hooks()
     N, P = 3, 700
-    g = torch.Generator().manual_seed(pooled[0] * 131 + ratio * 17 + int(aligned) + 2 * int(tiny))
+    nonfinite = tiny == "nonfinite"
+    tiny = tiny is True
+    g = torch.Generator().manual_seed(pooled[0] * 131 + ratio * 17 + int(aligned) + 2 * int(tiny) + 5 * int(nonfinite))
     feats = [(torch.randn(N, 200 >> l, 256 >> l, 256, generator=g) * (2e-6 if tiny else 1.0)).half().cuda() for l in range(4)]
     feats[2][:, 5:9, 3:11] = 0
+    if nonfinite:
+        for l, f in enumerate(feats):
+            n_bad = 400 >> l
+            iy = torch.randint(0, f.shape[1], (n_bad,), generator=g)
+            ix = torch.randint(0, f.shape[2], (n_bad,), generator=g)
+            ic = torch.randint(0, 256, (n_bad,), generator=g)
+            im = torch.randint(0, N, (n_bad,), generator=g)
+            vals = torch.tensor([float("inf"), float("-inf"), float("nan")])[torch.randint(0, 3, (n_bad,), generator=g)].half().cuda()
+            f[im.cuda(), iy.cuda(), ix.cuda(), ic.cuda()] = vals
+            f[N - 1, -1, -1, :] = float("inf")       # the level's last pixel
+            f[:, :, -1, 7] = float("nan")           # a whole last column of one channel: every right-edge bin's neighbour
+            f[:, 0, 0, :] = 1.0                     # pixel (0, 0) stays finite: the reference's CPU kernel gives an out-of-image SAMPLE weight 0 at
+                                                    # position 0 (ROIAlign_cpu.cpp:60-70) and multiplies - its CUDA twin skips the sample, as this kernel does
     ctr = torch.rand(N, P, 2, generator=g) * torch.tensor([1100.0, 860.0]) - torch.tensor([40.0, 30.0])
     wh = torch.exp(torch.rand(N, P, 2, generator=g) * 7.0 - 0.5)              # 0.6 .. 660 px, independent sides: elongated boxes too
     boxes = torch.cat([ctr - wh / 2, ctr + wh / 2], dim=2)
@@ -859,9 +880,33 @@ def test_roi_align_fast_form_is_bit_identical(L, pooled, ratio, aligned, tiny):
             for fast in (1, 0):
                 H.pe_test_set_roi_fast(fast)
                 outs.append([L.roi_align_nhwc(case["feats"], boxes, sort=s, **kw) for s in (False, True)])
-            assert torch.equal(outs[0][0].view(torch.int16), outs[1][0].view(torch.int16))
-            assert torch.equal(outs[0][1].view(torch.int16), outs[1][1].view(torch.int16))
-            assert float(outs[0][0].float().abs().sum()) > 0
+            def why(x, y):      # where two results differ: how many elements, and of which kind
+                d = x.view(torch.int16) != y.view(torch.int16)
+                xf, yf = x.float()[d], y.float()[d]
+                return {"differing": int(d.sum()), "both_nan": int((torch.isnan(xf) & torch.isnan(yf)).sum()), "fast_finite_other_not": int((torch.isfinite(xf) & ~torch.isfinite(yf)).sum()),
+                        "other_finite_fast_not": int((~torch.isfinite(xf) & torch.isfinite(yf)).sum()), "inf_vs_nan": int((torch.isinf(xf) != torch.isinf(yf)).sum()),
+                        "first": (xf[:4].tolist(), yf[:4].tolist(), x.view(torch.int16)[d][:4].tolist(), y.view(torch.int16)[d][:4].tolist())}
+            assert torch.equal(outs[0][0].view(torch.int16), outs[1][0].view(torch.int16)), why(outs[0][0], outs[1][0])
+            assert torch.equal(outs[0][1].view(torch.int16), outs[1][1].view(torch.int16)), why(outs[0][1], outs[1][1])
+            if nonfinite:
+                bad = ~torch.isfinite(outs[0][0].float())
+                assert 0 < int(bad.sum()) < bad.numel() // 4      # some bins sample a poisoned pixel, most do not
+                if len(case["feats"]) == 1 and len(case["scales"]) == 1 and case["scales"][0] == 1 / 4:
+                    # which bins those are is the reference's business: the oracle (restatement of ROIAlign_cpu.cpp) on the same fp16
+                    # features in fp32 must be non-finite in exactly the same (roi, bin, channel) places - a window's padding, a
+                    # neighbour bin's column or what lies behind the level never shows
+                    from oracle import roi_align as RA
+                    f = case["feats"][0].float().cpu().permute(0, 3, 1, 2).contiguous()
+                    cnt = counts.cpu().tolist()
+                    rois = torch.cat([torch.cat([torch.full((cnt[i], 1), float(i)), boxes[i, :cnt[i]].cpu()], 1) for i in range(N)])
+                    ref = RA.roi_align_forward(f, rois, 1 / 4, pooled[0], pooled[1], ratio, aligned).permute(0, 2, 3, 1)
+                    got = torch.cat([outs[0][0].view(N, P, pooled[0], pooled[1], 256)[i, :cnt[i]] for i in range(N)]).float().cpu()
+                    fg, fr = torch.isfinite(got), torch.isfinite(ref)
+                    assert torch.equal(fg, fr), {"hip_only_nonfinite": int((~fg & fr).sum()), "oracle_only_nonfinite": int((fg & ~fr).sum()), "where": (~fg & fr).nonzero()[:5].tolist() + (fg & ~fr).nonzero()[:5].tolist()}
+                    # (WHICH non-finite value a poisoned bin holds may differ: the reference multiplies every sample's four taps one by
+                    # one - a zero-weight tap on an Inf pixel makes NaN -, the table form multiplies a pixel's SUMMED weight once - Inf)
+            else:
+                assert float(outs[0][0].float().abs().sum()) > 0
     finally:
         H.pe_test_set_roi_fast(1)
 
