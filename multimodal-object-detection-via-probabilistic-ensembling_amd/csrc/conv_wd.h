@@ -27,6 +27,8 @@
 #pragma once
 #include <hip/hip_fp16.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace pe {
@@ -84,8 +86,10 @@ __host__ __device__ inline int k3x3_of_kseq(int kseq, int Cin, int e) {
 // ------------------------------------------------------------------------------------------------------
 // 3x3, stride 1, pad 1.  Block = WM x WN waves; wave (wm, wn) owns pixels [wm*TPX*32, +TPX*32) x channels [wn*64, +64).
 // ------------------------------------------------------------------------------------------------------
-// ABL (measurement builds only, results wrong): 1 = no weight loads in the loop, 2 = no LDS fragment reads in the loop,
-// 4 = no slab traffic and no barrier in the loop
+// ABL (measurement builds only, results wrong; instantiated by scripts/ probes and the -DPE_LAB library, never by the product): 1 = no weight
+// loads in the loop, 2 = no LDS fragment reads in the loop, 4 = no slab traffic and no barrier in the loop, 8 (HEAD == 2) = every conv3
+// chunk's K-loop runs twice and 64 KiB more lines are stored per tile: what a fused NEXT conv1 (1024 -> 256) would add in MFMAs, weight
+// records, fragment reads and stores if its 128 accumulators and its 64 KiB exchange tile were free
 // HEAD: the StandardRPNHead form (proposal_generator/rpn.py:74-85): the ReLU'd 3x3 output t never goes to memory; each wave
 // multiplies its 64 channels of t - the accumulators, converted to fp16, ARE MFMA B fragments when the head weight's K order
 // is packed to match - with the 15 x 256 objectness / delta weights, the four partial [128 px x 16] sums are added through LDS
@@ -417,42 +421,49 @@ __global__ __launch_bounds__(64 * WM * WN, (TPX <= 4 ? 2 : 1)) void conv3x3_wd_k
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
+            // the chunk's 16 K-steps.  SC (compile time): with the shortcut pipeline - false only in the LAB pricing build (ABL & 8), which
+            // runs the K-loop a second time on the same fragments to price the MFMA / weight-stream / fragment-read work of a fused NEXT conv1
+            auto chunk_ksteps = [&](auto sc_tag, int wbase) {
+                constexpr bool SC = decltype(sc_tag)::value;
 #pragma unroll
-            for (int ks = 0; ks < 16; ++ks) {
-                if ((ks & 3) == 0) r_load(((ks >> 2) + 1) & 1, c * 4 + (ks >> 2) + 1);   // the NEXT quarter (may belong to the next chunk)
-                if (ks + 1 < 16) {
+                for (int ks = 0; ks < 16; ++ks) {
+                    if (SC && (ks & 3) == 0) r_load(((ks >> 2) + 1) & 1, c * 4 + (ks >> 2) + 1);   // the NEXT quarter (may belong to the next chunk)
+                    if (ks + 1 < 16) {
 #pragma unroll
-                    for (int i = 0; i < TPX; ++i) pf[(ks + 1) & 1][i] = *reinterpret_cast<const half8*>(smem + tb[i] + (ks + 1) * 32);
-                } else {
+                        for (int i = 0; i < TPX; ++i) pf[(ks + 1) & 1][i] = *reinterpret_cast<const half8*>(smem + tb[i] + (ks + 1) * 32);
+                    } else {
 #pragma unroll
-                    for (int i = 0; i < TPX; ++i) pf[(ks + 1) & 1][i] = *reinterpret_cast<const half8*>(smem + tb[i]);
-                }
+                        for (int i = 0; i < TPX; ++i) pf[(ks + 1) & 1][i] = *reinterpret_cast<const half8*>(smem + tb[i]);
+                    }
 #pragma unroll
-                for (int blk = 0; blk < 2; ++blk)
+                    for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
-                    for (int i = 0; i < TPX; ++i)
-                        acc[blk][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks & 1][blk], pf[ks & 1][i], acc[blk][i], 0, 0, 0);
-                t_load(ks & 1, c * 16 + ks + 2);
+                        for (int i = 0; i < TPX; ++i)
+                            acc[blk][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks & 1][blk], pf[ks & 1][i], acc[blk][i], 0, 0, 0);
+                    t_load(ks & 1, wbase + ks + 2);
 #pragma unroll
-                for (int i = 0; i < TPX; ++i) {
+                    for (int i = 0; i < TPX; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                }
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, TPX - 2, 0);
-                if ((ks & 3) == 0) __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                if ((ks & 3) == 3) {
-                    const int q = ks >> 2;
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, TPX - 2, 0);
+                    if (SC && (ks & 3) == 0) __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (SC && (ks & 3) == 3) {
+                        const int q = ks >> 2;
 #pragma unroll
-                    for (int i = 0; i < TPX; ++i)
+                        for (int i = 0; i < TPX; ++i)
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) acc[q >> 1][i][(q & 1) * 8 + e] += (float)rv[q & 1][i][e];
+                            for (int e = 0; e < 8; ++e) acc[q >> 1][i][(q & 1) * 8 + e] += (float)rv[q & 1][i][e];
+                    }
                 }
-            }
+            };
+            if constexpr ((ABL & 8) != 0) chunk_ksteps(std::false_type{}, c * 16);      // LAB: a second pass over the chunk (results wrong)
+            chunk_ksteps(std::true_type{}, c * 16);
             // chunk epilogue: ReLU, fp16.  A lane owns 64 B of a pixel's 128-byte line (this wave's 64 outputs of the chunk); stored
             // straight from that layout every instruction scatters 16-byte pieces over 64 lines (r02 / r03).  Now half a pixel block
             // (16 lines) at a time goes through a wave-private 2 KiB LDS patch (piece p of row px in slot p ^ (px & 7)) and leaves
@@ -490,6 +501,10 @@ __global__ __launch_bounds__(64 * WM * WN, (TPX <= 4 ? 2 : 1)) void conv3x3_wd_k
                         const int m = m0 + i * 32 + h2 * 16 + r * 8 + rrow;      // rows >= M: beyond the buffer's records, dropped
                         const unsigned off = (unsigned)m * (unsigned)(a.tail_cout * 2) + lb;
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4v, v), rto, off, 0, 2);      // aux 2 = nt
+                        if constexpr ((ABL & 8) != 0) {      // LAB: the NEXT conv1's output lines (128 px x 512 B per tile), here a copy of chunk wn
+                            if (c == wn && a.out != nullptr && m < a.M)
+                                *reinterpret_cast<uint4v*>(reinterpret_cast<unsigned char*>(a.out) + (size_t)m * 512 + wn * 128 + rc * 16) = __builtin_bit_cast(uint4v, v);
+                        }
                     }
                     __builtin_amdgcn_wave_barrier();      // the next half's writers overwrite rows the other lanes have just read
                 }

@@ -130,3 +130,22 @@ extern "C" int pe_bottleneck_tail_wd_f16(const void* input, const void* packed_w
     PE_CHECK_LAUNCH("pe_bottleneck_tail_wd_f16");
     return PE_OK;
 }
+
+#ifdef PE_LAB
+// LAB library only (python -m proben_amd.build --lab): the fused tail with the work of a fused NEXT conv1 added on garbage (conv_wd.h, ABL & 8;
+// results WRONG) - scripts/lab/r06_tail_next_pricing.py.  `next_out`: [M, 256] fp16 scratch for the extra lines.
+extern "C" int pe_lab_bottleneck_tail_next_pricing(const void* input, const void* packed_weight3x3, const float* bias3x3, const void* packed_tail,
+                                                   const float* tail_bias, const void* residual, void* output, void* next_out, int32_t N,
+                                                   int32_t H, int32_t W, int32_t Cin, int32_t tail_cout, void* stream) {
+    const long long M = (long long)N * H * W;
+    pe::ConvWdArgs a{};
+    a.in = (const _Float16*)input; a.wpk = (const _Float16*)packed_weight3x3; a.bias = bias3x3; a.out = (_Float16*)next_out;
+    a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = 256; a.M = (int)M; a.relu = 1; a.out_stride = 256;
+    a.tail_w = (const _Float16*)packed_tail; a.tail_b = tail_bias; a.tail_res = (const _Float16*)residual;
+    a.tail_out = (_Float16*)output; a.tail_cout = tail_cout;
+    const int st = wd::launch_conv3x3_wd<1, 4, 4, 4, 8, 2>(a, (hipStream_t)stream);
+    if (st != PE_OK) return st;
+    PE_CHECK_LAUNCH("pe_lab_bottleneck_tail_next_pricing");
+    return PE_OK;
+}
+#endif
