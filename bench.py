@@ -407,7 +407,7 @@ def proben_micro(device, B=4096, reps=20):
 class BoardPower:
     """rocm-smi polled by ONE helper process (started before the timed region: no fork from this process, no Python thread, while the
     steps are being timed) on rank 0's device: board power and shader clock.  The hot kernels of this path run AT the board's power cap
-    (profiles/r04_power_kernels.txt, DESIGN.md 10.3): the cap, not the nominal MFMA peak, is what bounds them, so the line reports it.
+    (profiles/r04_power_kernels.txt, DESIGN.md 8.1): the cap, not the nominal MFMA peak, is what bounds them, so the line reports it.
     Best effort: no rocm-smi -> {"available": false}."""
 
     def __init__(self, device_index):

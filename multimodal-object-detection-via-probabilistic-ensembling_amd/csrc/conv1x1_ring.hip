@@ -16,7 +16,7 @@
 //     three stages (48 KiB) ahead of the consumers; wave 9 is the WEIGHT loader: a 3-stage ring of 32 KiB (L2-resident), two ahead.
 //     Both rings run on across tile boundaries, so the next tile's first slabs land while the consumers store this tile;
 //   * waves 0-7 (2 x 4, each 64 pixels x 64 channels = four 32x32 accumulators) issue NO vector-memory instruction in the K-loop:
-//     the loaders eat the 100-170-cycle issue stalls of a loaded memory pipe (DESIGN 9.2), the matrix waves only ds_read + MFMA;
+//     the loaders eat the 100-170-cycle issue stalls of a loaded memory pipe (DESIGN 8.4), the matrix waves only ds_read + MFMA;
 //   * one s_barrier per K-step: it publishes stage s (the loaders waited for their own vmcnt) and tells the loaders that every consumer
 //     is done with stage s - 1, which is exactly the ring slot their next DMA overwrites;
 //   * out-of-run / out-of-image pixel rows use an out-of-range buffer offset: the bounds check returns zeros and fetches nothing;
@@ -62,7 +62,7 @@ struct RingArgs {
                    // 4 = no ds_read / MFMA, 8 = no stores, 16 = pixel slabs fetched as if the input were K-chunk-major [K / 64][M][64]
 #endif
 };
-// The measurement switches of DESIGN 11.1's ablation budget exist in the lab library only: the product object contains no such branch
+// The measurement switches of DESIGN 8.6's ablation budget exist in the lab library only: the product object contains no such branch
 // (tests/test_build_audit.py::test_product_library_has_no_measurement_switches).
 #ifdef PE_LAB
 #define RG_ABL(bits) ((a.abl & (bits)) != 0)
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(RG_THREADS) void conv1x1_ring_kernel(RingArgs a) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     // Residual of the tile in ACCUMULATOR layout (a lane's 16 consecutive channels of its pixel = two 16-byte pieces per accumulator tile; loads
-    // tolerate that pattern - the L1 merges a lane's pieces, DESIGN 7.5 - stores do not), requested under the tile's last K-step like the bias.
+    // tolerate that pattern - the L1 merges a lane's pieces, DESIGN 8.3 - stores do not), requested under the tile's last K-step like the bias.
     half8 rv[RES ? 2 : 1][2][2];
     auto res_issue = [&](int nn, int mtile) {
         const int mrow0 = (b0 + 4 * mtile) * 32;

@@ -4,7 +4,7 @@
 // layers/batch_norm.py:45-65 FrozenBatchNorm2d folded + relu_; backbone/resnet.py:205-221, backbone/fpn.py:127-137,
 // proposal_generator/rpn.py:74-85).
 //
-// What the round-1 measurements said (DESIGN.md 7): every LDS-staged variant ends LDS-port bound - per 256x256x64
+// What the round-1 measurements said (DESIGN.md 8.2): every LDS-staged variant ends LDS-port bound - per 256x256x64
 // step the LDS absorbs 64 KiB of DMA writes at ~64 B/clk plus 192 KiB of fragment reads against 2048 clk of MFMA.
 // The weight tile is the larger half of that traffic although weights are STATIC.  So here:
 //   * weights never touch LDS.  They are pre-packed ONCE (pe_conv_wd_pack_weights) in MFMA A-fragment order:
@@ -89,7 +89,7 @@ __host__ __device__ inline int k3x3_of_kseq(int kseq, int Cin, int e) {
 // ABL (measurement builds only, results wrong; instantiated by scripts/ probes and the -DPE_LAB library, never by the product): 1 = no weight
 // loads in the loop, 2 = no LDS fragment reads in the loop, 4 = no slab traffic and no barrier in the loop, 8 (HEAD == 2) = every conv3
 // chunk's K-loop runs twice and 64 KiB more lines are stored per tile: what a fused NEXT conv1 (1024 -> 256) would add in MFMAs, weight
-// records, fragment reads and stores if its 128 accumulators and its 64 KiB exchange tile were free (DESIGN 12.1)
+// records, fragment reads and stores if its 128 accumulators and its 64 KiB exchange tile were free (DESIGN 9.1)
 // HEAD: the StandardRPNHead form (proposal_generator/rpn.py:74-85): the ReLU'd 3x3 output t never goes to memory; each wave
 // multiplies its 64 channels of t - the accumulators, converted to fp16, ARE MFMA B fragments when the head weight's K order
 // is packed to match - with the 15 x 256 objectness / delta weights, the four partial [128 px x 16] sums are added through LDS

@@ -6,7 +6,7 @@
 // (pe_conv_wd_pack_weights) in the same K order and summation order (accumulators start at zero, bias added in the epilogue), so
 // results are BIT-IDENTICAL to conv3x3_wd_kernel<1,4,4,4>.
 //
-// What changes against conv_wd.h and why (DESIGN.md 10):
+// What changes against conv_wd.h and why (DESIGN.md 8.2):
 //   * a wave owns TPX = 8 pixel blocks x 64 output channels = 256 fp32 accumulators - twice the pixels per weight record, i.e.
 //     HALF the L2 -> VGPR weight stream per MFMA, the biggest consumer of the CU's vector-memory issue path (bare loop: 1524-1569 vs
 //     1350 TFLOP/s).  The accumulators are the AGPRs a[0:255], addressed LITERALLY from inline-asm MFMAs: the register allocator

@@ -13,7 +13,7 @@
 //     The SHORTCUT enters through the matrix pipe: its 16-byte pieces are loaded straight into MFMA B-fragment layout (lane =
 //     pixel, 8 channels) and multiplied by two constant 0/1 fragments, so the fp32 add costs no VALU and no accumulator read; the
 //     loads of a whole chunk (96 VGPRs) are requested a chunk ahead of their use - a lane's four pieces of a line together, which
-//     the 241-register two-wave kernel could not afford (DESIGN.md 9.1: its quarter-order reads re-fetched 1.3x);
+//     the 241-register two-wave kernel could not afford (DESIGN.md 8.3: its quarter-order reads re-fetched 1.3x);
 //   * the output leaves as whole 128-byte lines through a wave-private LDS patch;
 //   * LDS map (160 KiB): T = [0, 96 Ki) holds t during phase B; the slab ring of phase A is {S0 = [96 Ki, 128 Ki), S1 = [128 Ki,
 //     160 Ki), T0 = [0, 32 Ki)} with slab g in slot g % 3.  The next tile's slab 0 is DMAed into S0 during this tile's group

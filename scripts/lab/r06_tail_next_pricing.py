@@ -1,6 +1,6 @@
 """Round 6, VERDICT r05 item 1: what would a NEXT epilogue in the fused res4 tail cost - the next block's conv1 (1024 -> 256) multiplied
 into the tail's conv3 phase, so that the 44 ring-kernel launches per step that re-read the 210 MB block output disappear?
-Registers and LDS do not close at two waves per SIMD (DESIGN 12.1), so this PRICES the idea before anything is built: the LAB library's
+Registers and LDS do not close at two waves per SIMD (DESIGN 9.1), so this PRICES the idea before anything is built: the LAB library's
 `pe_lab_bottleneck_tail_next_pricing` (conv_wd.h, ABL & 8; results wrong) runs every conv3 chunk's K-loop twice - the second pass is the
 MFMA / weight-record / fragment-read diet of the NEXT product (same 33.5 M MAC per tile, same 128 KiB of L2 records per wave) - and
 stores 64 KiB more whole lines per tile (the 256-channel conv1 output), as if the 128 extra accumulators and the 64 KiB exchange tile

@@ -1,6 +1,6 @@
 // Round 3, VERDICT r02 item 1: can ONE CU run an MFMA-bound wave set and an HBM-bound wave set at the same time and keep
 // both rates - i.e. is an "alternate phases by construction" schedule of the fused bottleneck tail worth building - or does
-// the chip's power management give the overlap back as clock (DESIGN 7.1 / 7.6)?
+// the chip's power management give the overlap back as clock (DESIGN 8.1 / 8.4)?
 //
 // One 512-thread workgroup per CU (2 waves / SIMD, like the conv kernels).  Waves 0-3 ("matrix set") run the 3x3 kernel's
 // K-step diet: 8 MFMA 32x32x16 f16 on conv-like operands + 4 ds_read_b128 + 2 L2-resident 1 KiB weight-record loads.

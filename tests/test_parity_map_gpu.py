@@ -7,7 +7,7 @@ detector are scored against the SAME ground truth with the same COCO evaluator (
 csrc/cocoeval.cpp) and the AP tables are compared.  The measurement itself lives in tests/parity_map.py; scripts/map_parity.py
 writes its record for profiles/ (this file only asserts).
 
-What the numbers mean (DESIGN.md 10.5, profiles/r04_map_parity.json, profiles/r04_map_fp16_ablation.json): on ONE 256-frame set the AP
+What the numbers mean (DESIGN.md 4, profiles/r04_map_parity.json, profiles/r04_map_fp16_ablation.json): on ONE 256-frame set the AP
 figures of the two detectors differ by a few tenths of a point with either sign - the ORACLE with fp16 rounding emulated at the device's
 storage points scatters the same way (+0.22 / +0.32 / +0.31 on the fixture set) - and over TEN disjoint sets (round 5: 2 560 frames,
 15 184 objects; profiles/r05_map_flips.json) the differences average out: mean dAP -0.05 (std over sets 0.18), dAP50 -0.08 (0.24),
