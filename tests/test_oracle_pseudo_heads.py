@@ -53,3 +53,52 @@ def test_fixture_rows_and_table_reproduce(golden_dir):
     np.testing.assert_allclose(o["boxes"].numpy(), want[:, 1:5], rtol=0, atol=2e-2)
     np.testing.assert_allclose(o["scores"].numpy(), want[:, 5], rtol=0, atol=2e-4)
     np.testing.assert_array_equal(o["classes"].numpy(), want[:, 6].astype(np.int64))
+
+
+def test_fused_map_fixture_is_consistent(golden_dir):
+    """tests/golden/fused_map_sets.npz (gen_fused_map.py: the oracle's rows of BOTH pseudo-trained detectors, with class probabilities and
+    variances, on the disjoint evaluation sets) against what is already pinned: the thermal detector's rows are the committed single-detector
+    rows bit for bit (same weights, same frames); a row's score is its class's probability; the RGB detector's first frame re-derives from
+    the committed RGB heads; and the oracle route (oracle.proben on the two lists) gives a fused AP table with the NaN scores the
+    reference's own `1 - sum(p)` background makes (demo_probEn.py:32-42) ordered last by both evaluators alike."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import proben_amd  # noqa: F401
+    from PIL import Image
+    from oracle import detector as D
+    from parity_map import FUSED_METHODS, coco_stats, load_fused_fixture, oracle_fused_rows
+    from proben_amd.data import resize_shortest_edge_shape
+    e = np.load(os.path.join(golden_dir, "fused_map_sets.npz"))
+    single = np.load(os.path.join(golden_dir, "pseudo_heads_r101.npz"))
+    more = np.load(os.path.join(golden_dir, "pseudo_heads_r101_sets.npz"))
+    assert np.array_equal(e["t_7002"][:, :7], single["oracle_rows"])
+    for k in e.files:
+        if k.startswith("t_") and "rows_" + k[2:] in more.files:
+            assert np.array_equal(e[k][:, :7], more["rows_" + k[2:]]), k
+        if k[:2] in ("t_", "r_"):
+            r = e[k]
+            assert r.shape[1] == 11 and np.array_equal(r[:, 5], r[np.arange(len(r)), 7 + r[:, 6].astype(int)]), k      # score = prob[class]
+            assert (r[:, 10] > 0).all(), k                                                                              # variance = exp(.)
+    sds, sets = load_fused_fixture(golden_dir)
+    assert len(sets) >= 4, "at least four evaluation sets with both detectors' rows"
+    name, ft, fr, gts, ot, orr = sets[0]
+    # the RGB detector's first frame through the oracle (the thermal one is covered by the test above)
+    new_hw = resize_shortest_edge_shape(512, 640, 800, 1333)
+    img = np.array(Image.fromarray(fr[0]).resize((new_hw[1], new_hw[0]), Image.BILINEAR))
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    o = D.forward([torch.from_numpy(img).permute(2, 0, 1).float().contiguous()], sds[1], D.DetectorSpec(depth=101), out_sizes=[(512, 640)])[0]
+    want = orr[orr[:, 0] == 0]
+    assert len(o["scores"]) == len(want) > 5
+    np.testing.assert_allclose(o["boxes"].numpy(), want[:, 1:5], rtol=0, atol=2e-2)
+    np.testing.assert_allclose(o["prob_score"].numpy(), want[:, 7:10], rtol=0, atol=2e-4)
+    np.testing.assert_allclose(o["vars"].numpy().reshape(-1), want[:, 10], rtol=1e-3, atol=0)
+    # the oracle route on one set: a detector pair worth fusing, and NaN rows that do not disturb the order of the others
+    for method in FUSED_METHODS:
+        rows = oracle_fused_rows(ot, orr, len(ft), method)
+        stats = coco_stats(gts, rows)
+        assert stats[1] > 0.7, (method, stats[:3])
+        nan = np.isnan(rows[:, 5])
+        if method[0] == "probEn":
+            assert 0 < nan.sum() < 0.01 * len(rows)          # a handful of members with 1 - sum(p) < 0
+            moved = np.concatenate([rows[~nan], rows[nan]])   # NaN rows at the end of the file instead of in place: they sort last either way
+            assert np.array_equal(coco_stats(gts, moved), stats)
