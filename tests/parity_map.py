@@ -188,35 +188,47 @@ def oracle_fused_rows(rows_t, rows_r, n_frames, method):
     return np.asarray(out, dtype=np.float32).reshape(-1, 7)
 
 
-def hip_fused_rows(models, frames_t, frames_r, method, batch=16, keep_inputs=False):
-    """The product route of configs[2]: FramePairPipeline (both detectors on their streams -> pe_proben_pack_detections ->
-    pe_proben_fuse_batch) -> the fused rows of every frame.  keep_inputs: also the two detectors' own rows (for the flip analysis)."""
+def hip_detections(models, frames_t, frames_r, batch=16):
+    """Both detectors on every frame pair through the product's FramePairPipeline (each on its own stream): the per-batch result dicts,
+    left on the device."""
     from proben_amd.data import resize_shortest_edge_shape
-    from proben_amd.fusion import check_candidate_overflow
     from proben_amd.pipeline import FramePairPipeline
     new_hw = resize_shortest_edge_shape(512, 640, 800, 1333)
-    pipe = FramePairPipeline(models, method[0], method[1])
-    rows, det_rows = [], [[], []]
+    pipe = FramePairPipeline(models, fuse=False)
+    out = []
     for b0 in range(0, len(frames_t), batch):
         ft, fr = torch.from_numpy(frames_t[b0:b0 + batch]).cuda(), torch.from_numpy(frames_r[b0:b0 + batch]).cuda()
-        dets, fused = pipe([ft, fr], [(512, 640)] * len(ft), new_hw)
-        pipe.wait((dets, fused))
-        check_candidate_overflow(fused)
+        dets, _ = pipe([ft, fr], [(512, 640)] * len(ft), new_hw)
+        pipe.wait((dets, None))
+        out.append((b0, dets))
+    torch.cuda.synchronize()
+    return out
+
+
+def detector_rows(batches, which):
+    rows = []
+    for b0, dets in batches:
+        d = dets[which]
+        for i, c in enumerate(d["counts"].cpu().tolist()):
+            b_, s_, c_ = d["boxes"][i, :c].cpu().numpy(), d["scores"][i, :c].cpu().numpy(), d["classes"][i, :c].cpu().numpy()
+            rows += [[b0 + i, *b_[j], s_[j], c_[j]] for j in range(c)]
+    return np.asarray(rows, dtype=np.float32).reshape(-1, 7)
+
+
+def hip_fused_rows(batches, method):
+    """The product route of configs[2] behind the detectors: pe_proben_pack_detections -> pe_proben_fuse_batch (fusion.fuse_detections, what
+    FramePairPipeline calls) on the device-resident detection lists -> the fused rows of every frame, boxes in the float32 of `Instances`."""
+    from proben_amd import fusion as F
+    rows = []
+    for b0, dets in batches:
+        fused = F.fuse_detections(dets, method[0], method[1])
+        F.check_candidate_overflow(fused)
         cnt, off = fused["counts"].cpu().tolist(), fused["offsets"].cpu().tolist()
         bx, sc, cl = fused["boxes"].float().cpu().numpy(), fused["scores"].cpu().numpy(), fused["classes"].cpu().numpy()
         for i, (c, o) in enumerate(zip(cnt, off)):
             assert c >= 0, "a fused image ran out of rows"
             rows += [[b0 + i, *bx[o + j], sc[o + j], cl[o + j]] for j in range(c)]
-        if keep_inputs:
-            for d, acc in zip(dets, det_rows):
-                dc = d["counts"].cpu().tolist()
-                for i, c in enumerate(dc):
-                    b_, s_, c_ = d["boxes"][i, :c].cpu().numpy(), d["scores"][i, :c].cpu().numpy(), d["classes"][i, :c].cpu().numpy()
-                    acc += [[b0 + i, *b_[j], s_[j], c_[j]] for j in range(c)]
-    rows = np.asarray(rows, dtype=np.float32).reshape(-1, 7)
-    if keep_inputs:
-        return rows, [np.asarray(a, dtype=np.float32).reshape(-1, 7) for a in det_rows]
-    return rows
+    return np.asarray(rows, dtype=np.float32).reshape(-1, 7)
 
 
 def _iou_to(r, q):
@@ -281,21 +293,27 @@ def measure_fused(golden_dir, methods=FUSED_METHODS, flips=True):
     rec = {"models": "two R101-FPN, seeded random backbones (seeds 1 / 2), RPN + box predictor fitted on the thermal / RGB rendering of the same "
                      "scenes (tests/golden/gen_pseudo_heads.py, gen_fused_map.py; 20 % of the objects invisible to the RGB detector)",
            "north_star_tolerance_points": NORTH_STAR_POINTS, "methods": {}}
-    for method in methods:
-        mrec = {"sets": {}}
-        deltas, totals = [], {"oracle_only": {}, "hip_only": {}}
-        pool_gt, pool_o, pool_h, off = [], [], [], 0
-        for name, ft, fr, gts, ot, orr in sets:
-            n = len(ft)
+    per_method = {m: {"sets": {}, "deltas": [], "totals": {"oracle_only": {}, "hip_only": {}}, "pool_gt": [], "pool_o": [], "pool_h": []} for m in methods}
+    off = 0
+    for name, ft, fr, gts, ot, orr in sets:
+        n = len(ft)
+        batches = hip_detections(models, ft, fr)
+        ht, hr = detector_rows(batches, 0), detector_rows(batches, 1)
+        if flips:      # detector-level rows only one side has (same class, IoU >= 0.9), both detectors together
+            o_in_only = np.concatenate([ot[_unmatched(ot[:, :7], ht, n), :7], orr[_unmatched(orr[:, :7], hr, n), :7]])
+            h_in_only = np.concatenate([ht[_unmatched(ht, ot[:, :7], n)], hr[_unmatched(hr, orr[:, :7], n)]])
+        for method in methods:
+            acc = per_method[method]
             ora = oracle_fused_rows(ot, orr, n, method)
-            hip, (ht, hr) = hip_fused_rows(models, ft, fr, method, keep_inputs=True)
+            hip = hip_fused_rows(batches, method)
             so, sh = coco_stats(gts, ora), coco_stats(gts, hip)
-            deltas.append((sh - so)[:6] * 100)
+            acc["deltas"].append((sh - so)[:6] * 100)
             ds, db, un_o, un_h = match_signed(ora, hip, n)
             srec = {"frames": n, "ground_truth_objects": int(sum(len(g[0]) for g in gts)), "oracle_fused_rows": int(len(ora)), "hip_fused_rows": int(len(hip)),
+                    "nan_scores": [int(np.isnan(ora[:, 5]).sum()), int(np.isnan(hip[:, 5]).sum())],
                     "oracle": {k: float(so[i] * 100) for i, k in enumerate(NAMES)}, "hip": {k: float(sh[i] * 100) for i, k in enumerate(NAMES)},
-                    "delta": {k: float(deltas[-1][i]) for i, k in enumerate(NAMES)}, "matched_pairs": int(len(ds)), "oracle_only": un_o, "hip_only": un_h,
-                    "matched_score_diff_sigma": float(ds.std()) if len(ds) else None,
+                    "delta": {k: float(acc["deltas"][-1][i]) for i, k in enumerate(NAMES)}, "matched_pairs": int(len(ds)), "oracle_only": un_o, "hip_only": un_h,
+                    "matched_score_diff_sigma": float(np.nanstd(ds)) if len(ds) else None,
                     "matched_box_abs_max_coord_median_px": float(np.median(np.abs(db).max(1))) if len(db) else None}
             if method == methods[0]:      # the detectors alone on the same frames (method-independent)
                 for tag, o_, h_ in (("thermal", ot[:, :7], ht), ("rgb", orr[:, :7], hr)):
@@ -303,35 +321,32 @@ def measure_fused(golden_dir, methods=FUSED_METHODS, flips=True):
                     srec["detector_" + tag] = {"oracle": {k: float(a[i] * 100) for i, k in enumerate(NAMES[:3])},
                                                "delta": {k: float((b[i] - a[i]) * 100) for i, k in enumerate(NAMES[:3])}}
             if flips:
-                # detector-level rows only one side has (same class, IoU >= 0.9), both detectors together
-                o_in, h_in = np.concatenate([ot[:, :7], orr[:, :7]]), np.concatenate([ht, hr])
-                o_in_only = np.concatenate([ot[_unmatched(ot[:, :7], ht, n), :7], orr[_unmatched(orr[:, :7], hr, n), :7]])
-                h_in_only = np.concatenate([ht[_unmatched(ht, ot[:, :7], n)], hr[_unmatched(hr, orr[:, :7], n)]])
                 co = classify_fused(ora, _unmatched(ora, hip, n), hip, o_in_only)
                 ch = classify_fused(hip, _unmatched(hip, ora, n), ora, h_in_only)
                 for key, cl in (("oracle_only", co), ("hip_only", ch)):
                     cnt = {}
                     for c in cl.values():
                         cnt[c] = cnt.get(c, 0) + 1
-                        totals[key][c] = totals[key].get(c, 0) + 1
+                        acc["totals"][key][c] = acc["totals"][key].get(c, 0) + 1
                     srec["flip_classes_" + key] = cnt
-                srec["detector_level_unmatched"] = {"oracle_only": int(len(o_in_only)), "hip_only": int(len(h_in_only)), "oracle_detections": int(len(o_in)),
-                                                    "hip_detections": int(len(h_in))}
-            mrec["sets"][name] = srec
-            pool_gt += list(gts)
-            for rows, pool in ((ora, pool_o), (hip, pool_h)):
+                srec["detector_level_unmatched"] = {"oracle_only": int(len(o_in_only)), "hip_only": int(len(h_in_only)), "oracle_detections": int(len(ot) + len(orr)),
+                                                    "hip_detections": int(len(ht) + len(hr))}
+            acc["sets"][name] = srec
+            acc["pool_gt"] += list(gts)
+            for rows, pool in ((ora, acc["pool_o"]), (hip, acc["pool_h"])):
                 r = rows.copy()
                 r[:, 0] += off
                 pool.append(r)
-            off += n
-        d = np.asarray(deltas)
-        mrec["n_sets"] = int(len(d))
-        mrec["delta_mean"] = {k: float(d[:, i].mean()) for i, k in enumerate(NAMES)}
-        mrec["delta_std"] = {k: float(d[:, i].std(ddof=1)) if len(d) > 1 else None for i, k in enumerate(NAMES)}
-        mrec["delta_standard_error"] = {k: float(d[:, i].std(ddof=1) / len(d) ** 0.5) if len(d) > 1 else None for i, k in enumerate(NAMES)}
-        po, ph = coco_stats(pool_gt, np.concatenate(pool_o)), coco_stats(pool_gt, np.concatenate(pool_h))
+        off += n
+    for method in methods:
+        acc = per_method[method]
+        d = np.asarray(acc["deltas"])
+        mrec = {"sets": acc["sets"], "n_sets": int(len(d)), "delta_mean": {k: float(d[:, i].mean()) for i, k in enumerate(NAMES)},
+                "delta_std": {k: float(d[:, i].std(ddof=1)) if len(d) > 1 else None for i, k in enumerate(NAMES)},
+                "delta_standard_error": {k: float(d[:, i].std(ddof=1) / len(d) ** 0.5) if len(d) > 1 else None for i, k in enumerate(NAMES)}}
+        po, ph = coco_stats(acc["pool_gt"], np.concatenate(acc["pool_o"])), coco_stats(acc["pool_gt"], np.concatenate(acc["pool_h"]))
         mrec["pooled"] = {"frames": off, "oracle": {k: float(po[i] * 100) for i, k in enumerate(NAMES)}, "delta": {k: float((ph[i] - po[i]) * 100) for i, k in enumerate(NAMES)}}
         if flips:
-            mrec["flip_class_totals"] = totals
+            mrec["flip_class_totals"] = acc["totals"]
         rec["methods"]["/".join(method)] = mrec
     return rec

