@@ -384,7 +384,7 @@ __global__ __launch_bounds__(RG_THREADS) void conv1x1_ring_kernel(RingArgs a) {
         if (mine >= 1 && !RG_ABL(4)) rg_compute<2>(acc, pa, pb, fswa, fswb, fkh);
         if (++ks == nk) {
             // ---- tile epilogue: + bias, ReLU, fp16, WHOLE 128-byte lines.  Stores straight from the accumulator layout are 16-byte
-            // pieces 512 B apart - 64 write requests per instruction, measured at 17 of the launch's 78 us (profiles/r05_ring_abl.txt).
+            // pieces 512 B apart - 64 write requests per instruction, measured at 17 of the launch's 78 us (profiles/r05_ring_abl_v1_piece_stores.txt).
             // After the end-of-tile barrier nobody reads the weight slot of the tile's last K-step any more, and its loader refills it
             // only behind the NEXT step's barrier, which the consumers reach after this epilogue: each wave transposes its 32 pixels x
             // 64 channels through a private 4 KiB patch of that slot (chunk c of row r in slot c ^ (r & 7)) and stores 8 whole lines

@@ -23,7 +23,7 @@ int pe_test_wd9_takes(int N, int H, int W, int Cin, int Cout);
 /* the same for the fused RPN head (pe_conv3x3_wd_rpn_head_f16) */
 int pe_test_wd9_head_takes(int N, int H, int W);
 /* workgroups of the persistent 3x3 kernels (multiples of 8 in 8 .. 256; 0 = leave unchanged; default 256 = one per CU): what leaving CUs
- * to the other detector's stream is worth (scripts/r04_ab2.sh); the second argument is ignored (it sized the round-4 tail kernel) */
+ * to the other detector's stream is worth (scripts/archive/r04_ab2.sh); the second argument is ignored (it sized the round-4 tail kernel) */
 int pe_test_set_wd9_wgs(int pure, int tail);
 /* workgroups of the persistent 1x1 ring kernel (default 256 = one per CU) */
 int pe_test_set_ring_wgs(int wgs);

@@ -2,7 +2,7 @@
 // kernel (conv_wd.h, HEAD = 2) vs the new one on res4 shapes - sampled fp64 check, full comparison against the shipped kernel's
 // output (same arithmetic up to summation order), timing, ablations and an s_memtime timeline.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -mllvm -amdgpu-spill-vgpr-to-agpr=0 -I include \
-//         -I multimodal-object-detection-via-probabilistic-ensembling_amd/csrc scripts/wd9_tail_probe.hip -o scripts/wd9_tail_probe
+//         -I multimodal-object-detection-via-probabilistic-ensembling_amd/csrc scripts/lab/wd9_tail_probe.hip -o scripts/wd9_tail_probe
 #include "conv_wd9_tail.h"
 
 #include <cmath>
