@@ -111,6 +111,15 @@ __device__ __forceinline__ void wd_sload4(float8v& a0, float8v& a1, float8v& b0,
                  : "=&s"(a0), "=&s"(a1), "=&s"(b0), "=&s"(b1)
                  : "s"(uni(pa)), "s"(uni(pb)));
 }
+#ifndef PE_EXP_TAIL_RES_AUX
+#define PE_EXP_TAIL_RES_AUX 0
+#endif
+#ifndef PE_EXP_TAIL_NORES
+#define PE_EXP_TAIL_NORES 0      // 1: shortcut loads all out of range (no traffic, results wrong); 2: every quarter re-reads quarter 0's lines
+#endif
+#ifndef PE_EXP_TAIL_NOSTORE
+#define PE_EXP_TAIL_NOSTORE 0
+#endif
 template <int WM, int WN, int TPX, int DEPTH, int ABL = 0, int HEAD = 0>
 __global__ __launch_bounds__(64 * WM * WN, (TPX <= 4 ? 2 : 1)) void conv3x3_wd_kernel(pe::ConvWdArgs a) {
     constexpr int THREADS = 64 * WM * WN;
@@ -384,7 +393,7 @@ __global__ __launch_bounds__(64 * WM * WN, (TPX <= 4 ? 2 : 1)) void conv3x3_wd_k
 #pragma unroll
         for (int i = 0; i < TPX; ++i) {
             const int m = m0 + i * 32 + (lane & 31);
-            rbase[i] = (a.tail_res && m < a.M) ? (unsigned)(((size_t)m * a.tail_cout + wn * (NCH * 64) + (lane >> 5) * 32) * 2) : 0xFFFFFFF0u;
+            rbase[i] = (a.tail_res && m < a.M && PE_EXP_TAIL_NORES != 1) ? (unsigned)(((size_t)m * a.tail_cout + wn * (NCH * 64) + (lane >> 5) * 32) * 2) : 0xFFFFFFF0u;
         }
         // shortcut quarters (8 of the lane's 32 outputs, all four pixel blocks) run as a rolling two-deep pipeline across the
         // chunks: global quarter g = 4 c + q is requested at K-step 4 g - 4 and added at 4 g + 3 (7 K-steps of HBM latency
@@ -395,7 +404,7 @@ __global__ __launch_bounds__(64 * WM * WN, (TPX <= 4 ? 2 : 1)) void conv3x3_wd_k
 #pragma unroll
             for (int i = 0; i < TPX; ++i)
                 rv[set][i] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(
-                    rr, (rbase[i] == 0xFFFFFFF0u || g >= 4 * NCH) ? 0xFFFFFFF0u : rbase[i] + (unsigned)((g >> 2) * 128 + (g & 3) * 16), 0, 0));
+                    rr, (rbase[i] == 0xFFFFFFF0u || g >= 4 * NCH) ? 0xFFFFFFF0u : (PE_EXP_TAIL_NORES == 2 ? (unsigned)(lane * 16 + i * 1024 + wn * 4096) : rbase[i] + (unsigned)((g >> 2) * 128 + (g & 3) * 16)), 0, PE_EXP_TAIL_RES_AUX));
         };
         r_load(0, 0);
         for (int c = 0; c < NCH; ++c) {
@@ -453,7 +462,7 @@ __global__ __launch_bounds__(64 * WM * WN, (TPX <= 4 ? 2 : 1)) void conv3x3_wd_k
                     __builtin_amdgcn_sched_group_barrier(0x008, TPX - 2, 0);
                     if (SC && (ks & 3) == 0) __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);
                     __builtin_amdgcn_sched_barrier(0);
-                    if (SC && (ks & 3) == 3) {
+                    if (SC && (ks & 3) == 3 && (PE_EXP_TAIL_NORES != 3 || a.N < 0)) {
                         const int q = ks >> 2;
 #pragma unroll
                         for (int i = 0; i < TPX; ++i)
@@ -499,7 +508,7 @@ __global__ __launch_bounds__(64 * WM * WN, (TPX <= 4 ? 2 : 1)) void conv3x3_wd_k
                     for (int r = 0; r < 2; ++r) {
                         const half8 v = *reinterpret_cast<const half8*>(patch + r * 1024 + lane * 16);
                         const int m = m0 + i * 32 + h2 * 16 + r * 8 + rrow;      // rows >= M: beyond the buffer's records, dropped
-                        const unsigned off = (unsigned)m * (unsigned)(a.tail_cout * 2) + lb;
+                        const unsigned off = PE_EXP_TAIL_NOSTORE ? 0xFFFFFFF0u : (unsigned)m * (unsigned)(a.tail_cout * 2) + lb;
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4v, v), rto, off, 0, 2);      // aux 2 = nt
                         if constexpr ((ABL & 8) != 0) {      // LAB: the NEXT conv1's output lines (128 px x 512 B per tile), here a copy of chunk wn
                             if (c == wn && a.out != nullptr && m < a.M)

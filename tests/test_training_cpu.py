@@ -82,9 +82,16 @@ def _ddp_worker(rank, world, port, tmp):
         flat.master.copy_(torch.randn(flat.numel, generator=g))
     red = BucketedGradAllReduce(flat, bucket_bytes=64)       # tiny buckets: several collectives per step
     x = torch.randn(9, 5, generator=torch.Generator().manual_seed(7 + rank))
+    # this rank's OWN gradient comes from a hook-free copy of the (broadcast) parameters: the reducer's buckets fire asynchronously during
+    # backward and sum into flat.grad in place, so a clone of flat.grad taken after backward() may already hold reduced buckets
+    plain = FlatParams(_SHAPES, "cpu")
+    with torch.no_grad():
+        plain.master.copy_(flat.master)
+    plain.zero_grad()
+    _toy(plain, x).backward()
+    own = plain.grad.clone()
     flat.zero_grad()
     _toy(flat, x).backward()
-    own = flat.grad.clone()
     scale = red.finish()
     torch.save({"master": flat.master.clone(), "own": own, "sum": flat.grad.clone(), "scale": scale, "order": red.last_order,
                 "buckets": red.buckets, "x": x}, os.path.join(tmp, f"r{rank}.pt"))
