@@ -53,18 +53,8 @@ struct B64Args {
     int tiles_x, tiles_y;
 };
 
-#ifndef PE_EXP_B64_OUT_AUX
-#define PE_EXP_B64_OUT_AUX 0
-#endif
-#ifndef PE_EXP_B64_T1N_AUX
-#define PE_EXP_B64_T1N_AUX 0
-#endif
-#ifndef PE_EXP_B64_RES_AUX
-#define PE_EXP_B64_RES_AUX 0
-#endif
-template <int AUX = 0>
 __device__ __forceinline__ half8 bload(const __amdgpu_buffer_rsrc_t& r, unsigned voff, int soff) {
-    return __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, AUX));
+    return __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
 
 typedef float float8v __attribute__((ext_vector_type(8)));
@@ -153,7 +143,7 @@ __global__ __launch_bounds__(256, 2) void bneck64_kernel(B64Args a) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const unsigned vo = pvalid[i] ? (SC ? poff[i] * 128u + h * 64 + q * 16 : poff[i] * 512u + c * 128 + h * 64 + q * 16) : 0xFFFFFFF0u;
-                rv[i][q] = bload<PE_EXP_B64_RES_AUX>(rres, vo, 0);
+                rv[i][q] = bload(rres, vo, 0);
             }
     };
     res_load(0);
@@ -320,7 +310,7 @@ __global__ __launch_bounds__(256, 2) void bneck64_kernel(B64Args a) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const half8 v = *reinterpret_cast<const half8*>(stg + (k * 8 + (lane >> 3)) * SROW + (lane & 7) * 16);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4v, v), rout, srow_off(k, 512u, c * 128), 0, PE_EXP_B64_OUT_AUX);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4v, v), rout, srow_off(k, 512u, c * 128), 0, 0);
         }
         if (NEXT) {   // B fragments of the chunk: read back from the staging patch (the lane's own 16-byte pieces) rather than kept in registers
 #pragma unroll
@@ -345,7 +335,7 @@ __global__ __launch_bounds__(256, 2) void bneck64_kernel(B64Args a) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const half8 v = *reinterpret_cast<const half8*>(stg + (k * 8 + (lane >> 3)) * SROW + (lane & 7) * 16);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4v, v), rt1n, srow_off(k, 128u, 0), 0, PE_EXP_B64_T1N_AUX);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4v, v), rt1n, srow_off(k, 128u, 0), 0, 0);
         }
     }
 }

@@ -83,55 +83,41 @@ __device__ __forceinline__ int4v rg_make_rsrc(const void* p, unsigned bytes) {
 // eight LDS-DMA pieces (64 lanes x 16 B each, lane-linear) at LDS byte addresses lds, lds + 1 KiB, ...; v0..v7 = per-lane byte offsets
 // into the buffer (>= 2 GiB: out of range -> the bounds check returns zeros), soff = wave-uniform byte offset.  M0 is compiler-reserved:
 // saved and restored inside the statement.
-#ifndef PE_EXP_RING_PIX_NT
-#define PE_EXP_RING_PIX_NT 0
-#endif
-#ifndef PE_EXP_RING_OUT_AUX
-#define PE_EXP_RING_OUT_AUX 0
-#endif
-#define RG_DMA_ASM(MOD)                                                                                             \
-        "s_mov_b32 %0, m0\n\t"                                                                                      \
-        "s_mov_b32 m0, %1\n\t"                                                                                      \
-        "s_nop 0\n\t"                                                                                               \
-        "buffer_load_dwordx4 %4, %2, %3 offen" MOD " lds\n\t"                                                       \
-        "s_add_u32 m0, m0, 0x400\n\t"                                                                               \
-        "s_nop 0\n\t"                                                                                               \
-        "buffer_load_dwordx4 %5, %2, %3 offen" MOD " lds\n\t"                                                       \
-        "s_add_u32 m0, m0, 0x400\n\t"                                                                               \
-        "s_nop 0\n\t"                                                                                               \
-        "buffer_load_dwordx4 %6, %2, %3 offen" MOD " lds\n\t"                                                       \
-        "s_add_u32 m0, m0, 0x400\n\t"                                                                               \
-        "s_nop 0\n\t"                                                                                               \
-        "buffer_load_dwordx4 %7, %2, %3 offen" MOD " lds\n\t"                                                       \
-        "s_add_u32 m0, m0, 0x400\n\t"                                                                               \
-        "s_nop 0\n\t"                                                                                               \
-        "buffer_load_dwordx4 %8, %2, %3 offen" MOD " lds\n\t"                                                       \
-        "s_add_u32 m0, m0, 0x400\n\t"                                                                               \
-        "s_nop 0\n\t"                                                                                               \
-        "buffer_load_dwordx4 %9, %2, %3 offen" MOD " lds\n\t"                                                       \
-        "s_add_u32 m0, m0, 0x400\n\t"                                                                               \
-        "s_nop 0\n\t"                                                                                               \
-        "buffer_load_dwordx4 %10, %2, %3 offen" MOD " lds\n\t"                                                      \
-        "s_add_u32 m0, m0, 0x400\n\t"                                                                               \
-        "s_nop 0\n\t"                                                                                               \
-        "buffer_load_dwordx4 %11, %2, %3 offen" MOD " lds\n\t"                                                      \
-        "s_mov_b32 m0, %0"
-template <bool NT = false>
 __device__ __forceinline__ void rg_dma8(unsigned lds, int4v rsrc, unsigned soff, unsigned v0, unsigned v1, unsigned v2, unsigned v3,
                                         unsigned v4, unsigned v5, unsigned v6, unsigned v7) {
     unsigned keep;
     lds = __builtin_amdgcn_readfirstlane(lds);       // wave-uniform by construction; the "s" constraint needs the compiler to know it
     soff = __builtin_amdgcn_readfirstlane(soff);
-    if constexpr (NT)
-        asm volatile(RG_DMA_ASM(" nt")
-                     : "=&s"(keep)
-                     : "s"(lds), "s"(rsrc), "s"(soff), "v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(v4), "v"(v5), "v"(v6), "v"(v7)
-                     : "scc");
-    else
-        asm volatile(RG_DMA_ASM("")
-                     : "=&s"(keep)
-                     : "s"(lds), "s"(rsrc), "s"(soff), "v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(v4), "v"(v5), "v"(v6), "v"(v7)
-                     : "scc");
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %1\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %4, %2, %3 offen lds\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %5, %2, %3 offen lds\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %6, %2, %3 offen lds\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %7, %2, %3 offen lds\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %8, %2, %3 offen lds\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %9, %2, %3 offen lds\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %10, %2, %3 offen lds\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %11, %2, %3 offen lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "s"(lds), "s"(rsrc), "s"(soff), "v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(v4), "v"(v5), "v"(v6), "v"(v7)
+        : "scc");
 }
 
 constexpr unsigned RG_OOB = 0x80000000u;
@@ -269,8 +255,8 @@ __global__ __launch_bounds__(RG_THREADS) void conv1x1_ring_kernel(RingArgs a) {
                 for (int q = 0; q < 16; ++q) vo[q] = (q * 8 + lrow < vrows) ? (unsigned)(q * 1024 + lane * 16) : RG_OOB;
             }
             if (!RG_ABL(1)) {
-                rg_dma8<PE_EXP_RING_PIX_NT != 0>(lds, rs, soff, vo[0], vo[1], vo[2], vo[3], vo[4], vo[5], vo[6], vo[7]);
-                rg_dma8<PE_EXP_RING_PIX_NT != 0>(lds + 8192, rs, soff, vo[8], vo[9], vo[10], vo[11], vo[12], vo[13], vo[14], vo[15]);
+                rg_dma8(lds, rs, soff, vo[0], vo[1], vo[2], vo[3], vo[4], vo[5], vo[6], vo[7]);
+                rg_dma8(lds + 8192, rs, soff, vo[8], vo[9], vo[10], vo[11], vo[12], vo[13], vo[14], vo[15]);
             }
             if (++u_ks == nk) {
                 u_ks = 0;
@@ -443,7 +429,7 @@ __global__ __launch_bounds__(RG_THREADS) void conv1x1_ring_kernel(RingArgs a) {
                     const int row = wm * 64 + i * 32 + r;
                     // rows beyond this tile's pixels (another workgroup's, or beyond M) get an out-of-range offset: the store is dropped
                     const unsigned off = row < vrows ? (unsigned)(((mrow0 + row) * a.out_stride + chw + ((rp ^ (rr & 7)) << 3)) * 2) : RG_OOB;
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4v, v), rout, off, 0, PE_EXP_RING_OUT_AUX);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4v, v), rout, off, 0, 0);
                 }
             }
             ks = 0;

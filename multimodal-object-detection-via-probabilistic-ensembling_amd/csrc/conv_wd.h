@@ -111,11 +111,12 @@ __device__ __forceinline__ void wd_sload4(float8v& a0, float8v& a1, float8v& b0,
                  : "=&s"(a0), "=&s"(a1), "=&s"(b0), "=&s"(b1)
                  : "s"(uni(pa)), "s"(uni(pb)));
 }
-#ifndef PE_EXP_TAIL_RES_AUX
-#define PE_EXP_TAIL_RES_AUX 0
-#endif
+// Diagnosis switches of the fused tail (variant libraries built by scripts/lab/build_variant.py only - the product object is
+// compiled with both at 0 and contains none of these branches; results are WRONG with any of them set).
+// PE_EXP_TAIL_NORES: 1 = shortcut loads all out of range (no traffic); 2 = every shortcut load reads a 16 KiB window (L1 hits); 3 = loads
+// issued, never added (no explicit wait); 4 = addresses folded into a 2 MiB window (L1 misses, L2 hits).  PE_EXP_TAIL_NOSTORE: stores dropped.
 #ifndef PE_EXP_TAIL_NORES
-#define PE_EXP_TAIL_NORES 0      // 1: shortcut loads all out of range (no traffic, results wrong); 2: every quarter re-reads quarter 0's lines
+#define PE_EXP_TAIL_NORES 0
 #endif
 #ifndef PE_EXP_TAIL_NOSTORE
 #define PE_EXP_TAIL_NOSTORE 0
@@ -379,8 +380,10 @@ __global__ __launch_bounds__(64 * WM * WN, (TPX <= 4 ? 2 : 1)) void conv3x3_wd_k
             wf[slot][0] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rt, lane * 16, so, 0));
             wf[slot][1] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rt, lane * 16 + 1024, so, 0));
         };
-        t_load(0, 0);     // conv3's weights are L2 resident: two K-steps of prefetch; the registers saved carry the shortcut pipeline
+        t_load(0, 0);     // four K-steps of weight prefetch, like the 3x3 phase (round 6; two until then)
         t_load(1, 1);
+        t_load(2, 2);
+        t_load(3, 3);
         int tb[TPX];
 #pragma unroll
         for (int i = 0; i < TPX; ++i) tb[i] = (i * 32 + (lane & 31)) * TROW + (lane >> 5) * 16;
@@ -404,7 +407,7 @@ __global__ __launch_bounds__(64 * WM * WN, (TPX <= 4 ? 2 : 1)) void conv3x3_wd_k
 #pragma unroll
             for (int i = 0; i < TPX; ++i)
                 rv[set][i] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(
-                    rr, (rbase[i] == 0xFFFFFFF0u || g >= 4 * NCH) ? 0xFFFFFFF0u : (PE_EXP_TAIL_NORES == 2 ? (unsigned)(lane * 16 + i * 1024 + wn * 4096) : rbase[i] + (unsigned)((g >> 2) * 128 + (g & 3) * 16)), 0, PE_EXP_TAIL_RES_AUX));
+                    rr, (rbase[i] == 0xFFFFFFF0u || g >= 4 * NCH) ? 0xFFFFFFF0u : (PE_EXP_TAIL_NORES == 2 ? (unsigned)(lane * 16 + i * 1024 + wn * 4096) : PE_EXP_TAIL_NORES == 4 ? ((rbase[i] + (unsigned)((g >> 2) * 128 + (g & 3) * 16)) & 0x1FFFFFu) : rbase[i] + (unsigned)((g >> 2) * 128 + (g & 3) * 16)), 0, 0));
         };
         r_load(0, 0);
         for (int c = 0; c < NCH; ++c) {
@@ -434,32 +437,29 @@ __global__ __launch_bounds__(64 * WM * WN, (TPX <= 4 ? 2 : 1)) void conv3x3_wd_k
             // runs the K-loop a second time on the same fragments to price the MFMA / weight-stream / fragment-read work of a fused NEXT conv1
             auto chunk_ksteps = [&](auto sc_tag, int wbase) {
                 constexpr bool SC = decltype(sc_tag)::value;
+                // Round 6 (profiles/r06_tail_tcp_diagnosis.txt): the shortcut's HBM misses sit in the same in-order vector-memory path as the
+                // weight records, so whatever is issued behind a shortcut request waits for it.  The K-step therefore (1) keeps FOUR K-steps of
+                // weights in flight (all of wf, as in the 3x3 phase), (2) issues the shortcut request AFTER its own weight loads - the first
+                // record that can be held up by the request is needed five K-steps later -, and (3) pays for the two extra weight slots with a
+                // SINGLE set of pixel fragments: pixel block i's two MFMAs are issued together and its next fragment is read right behind them
+                // (six MFMAs = 192 cycles before it is needed).  Same MFMAs on the same accumulators in the same K order, same shortcut adds at
+                // the same K-steps: same bits (tests/test_ops_gpu.py tail tests); -1.5 % per launch, +0.4 % in the pipeline.
 #pragma unroll
                 for (int ks = 0; ks < 16; ++ks) {
-                    if (SC && (ks & 3) == 0) r_load(((ks >> 2) + 1) & 1, c * 4 + (ks >> 2) + 1);   // the NEXT quarter (may belong to the next chunk)
-                    if (ks + 1 < 16) {
-#pragma unroll
-                        for (int i = 0; i < TPX; ++i) pf[(ks + 1) & 1][i] = *reinterpret_cast<const half8*>(smem + tb[i] + (ks + 1) * 32);
-                    } else {
-#pragma unroll
-                        for (int i = 0; i < TPX; ++i) pf[(ks + 1) & 1][i] = *reinterpret_cast<const half8*>(smem + tb[i]);
-                    }
-#pragma unroll
-                    for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-                        for (int i = 0; i < TPX; ++i)
-                            acc[blk][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks & 1][blk], pf[ks & 1][i], acc[blk][i], 0, 0, 0);
-                    t_load(ks & 1, wbase + ks + 2);
 #pragma unroll
                     for (int i = 0; i < TPX; ++i) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        acc[0][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks & 3][0], pf[0][i], acc[0][i], 0, 0, 0);
+                        acc[1][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks & 3][1], pf[0][i], acc[1][i], 0, 0, 0);
+                        pf[0][i] = *reinterpret_cast<const half8*>(smem + tb[i] + ((ks + 1) & 15) * 32);
+                    }
+                    t_load(ks & 3, wbase + ks + 4);
+                    if (SC && (ks & 3) == 0) r_load(((ks >> 2) + 1) & 1, c * 4 + (ks >> 2) + 1);   // the NEXT quarter (may belong to the next chunk)
+#pragma unroll
+                    for (int i = 0; i < TPX; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
                         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                     }
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, TPX - 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
                     if (SC && (ks & 3) == 0) __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);
                     __builtin_amdgcn_sched_barrier(0);
                     if (SC && (ks & 3) == 3 && (PE_EXP_TAIL_NORES != 3 || a.N < 0)) {
