@@ -50,8 +50,7 @@ def test_wd9_kernels_do_not_spill_and_leave_the_accumulation_registers_alone(tmp
 
 
 def test_two_wave_weights_direct_kernels_fit_two_per_simd_without_scratch(tmp_path):
-    """csrc/conv_wd.h's kernels run two waves per SIMD: 256 registers each and no scratch (the fused tail sits AT 256 since its
-    line-store epilogue; an edit that tips it over spills into scratch inside the chunk loop - it did during round 4)."""
+    """csrc/conv_wd.h's kernels run two waves per SIMD: 256 registers each and no scratch (the fused tail sits at 248 - 256 before round 6's single set of conv3 fragments -; an edit that tips it over spills into scratch inside the chunk loop - it did during round 4)."""
     import proben_amd  # noqa: F401
     from proben_amd import build
     src = os.path.join(build.CSRC, "conv_wd.hip")
