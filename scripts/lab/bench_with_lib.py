@@ -13,5 +13,7 @@ name = sys.argv[1]
 if name != "product":
     _lib.LIB_PATH = _lib.LIB_PATH.replace(".so", "_%s.so" % name)
     assert os.path.exists(_lib.LIB_PATH), _lib.LIB_PATH
+if os.environ.get("PE_RING_WGS"):      # lab: workgroups of the persistent 1x1 kernel (csrc/test_hooks.h)
+    _lib.test_hooks().pe_test_set_ring_wgs(int(os.environ["PE_RING_WGS"]))
 sys.argv = [os.path.join(ROOT, "bench.py")] + sys.argv[2:]
 runpy.run_path(sys.argv[0], run_name="__main__")

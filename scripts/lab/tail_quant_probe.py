@@ -12,15 +12,16 @@ rnd = lambda *s: torch.randn(*s, device="cuda")
 w2 = (rnd(C, 3, 3, C) / (C * 9) ** 0.5).half(); b2 = rnd(C) * 0.1
 w3 = (rnd(CT, C) / C ** 0.5).half(); b3 = rnd(CT) * 0.1
 pk2, pk3 = L.conv_wd_pack(w2), L.conv_wd_pack_tail(w3)
-def timed(fn, reps=40):
+REPS = int(os.environ.get('PE_REPS', '40'))
+def timed(fn, reps=REPS):
     for _ in range(5): fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e3
-for N in (10, 20, 21, 32, 40, 41, 61):
+for N in ([int(v) for v in sys.argv[2:]] or (10, 20, 21, 32, 40, 41, 61)):
     x = rnd(N, H, W, C).half().relu(); res = rnd(N, H, W, CT).half().relu()
     out = torch.empty(N, H, W, CT, device="cuda", dtype=torch.float16)
-    t = min(timed(lambda: L.bottleneck_tail_wd(x, pk2, b2, pk3, b3, res, CT, out=out)) for _ in range(3))
+    t = min(timed(lambda: L.bottleneck_tail_wd(x, pk2, b2, pk3, b3, res, CT, out=out)) for _ in range(3 if REPS >= 40 else 1))
     print("%s N=%2d tiles=%4d rounds=%.3f  %.1f us  = %.1f us per 512 tiles, %.0f TFLOP/s" % (sys.argv[1] if len(sys.argv) > 1 else "product", N, N * 25, N * 25 / 512, t, t / (N * 25 / 512), N * 3200 * 2 * (2304 * 256 + 256 * 1024) / t / 1e6))
