@@ -135,3 +135,12 @@ def test_product_library_has_no_measurement_switches(tmp_path):
     if os.path.exists(build.LIB):
         syms = subprocess.run(["nm", "-D", "--defined-only", build.LIB], capture_output=True, text=True).stdout
         assert "pe_test_set_ring_ablation" not in syms and "pe_conv_wd_set_concurrent_streams" not in syms
+    # round 6's diagnosis switches (PE_EXP_*: compile-time, variant libraries of scripts/lab/build_variant.py only) default to 0 in every source,
+    # and nothing in the product build defines one
+    for f in os.listdir(build.CSRC):
+        if f.endswith((".h", ".hip", ".cpp")):
+            for ln in open(os.path.join(build.CSRC, f)).read().splitlines():
+                m = re.match(r"\s*#define\s+(PE_EXP_\w+)\s+(\S+)", ln)
+                assert m is None or m.group(2) == "0", (f, ln)
+    assert "PE_EXP_" not in open(os.path.join(build.PKG, "build.py")).read()
+    assert not any("PE_EXP_" in flag for flags in build.EXTRA.values() for flag in flags)
