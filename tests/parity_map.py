@@ -139,8 +139,9 @@ def measure(golden_dir):
 FUSED_METHODS = (("probEn", "v-avg"), ("avg", "s-avg"))
 
 
-def load_fused_fixture(golden_dir):
-    """(state dicts (thermal, rgb), [(name, thermal frames, rgb frames, ground truth, oracle rows thermal, oracle rows rgb)])."""
+def load_fused_fixture(golden_dir, max_sets=None):
+    """(state dicts (thermal, rgb), [(name, thermal frames, rgb frames, ground truth, oracle rows thermal, oracle rows rgb)]).
+    `max_sets`: render only the first few sets' frames (the CPU consistency test needs one; rendering 24 sets takes a quarter of an hour on 8 cores)."""
     import proben_amd  # noqa: F401
     from proben_amd.synthetic import labelled_frames, labelled_frames_rgb, synthetic_state_dict
     sds = []
@@ -160,6 +161,8 @@ def load_fused_fixture(golden_dir):
             ft, gts = labelled_frames(n, seed=seed)
             fr, _ = labelled_frames_rgb(n, seed=seed)
             sets.append((f"seed {seed}", ft, fr, gts, e[k], e["r_" + k[2:]]))
+            if max_sets is not None and len(sets) >= max_sets:
+                break
     return sds, sets
 
 

@@ -84,8 +84,8 @@ def test_fused_map_fixture_is_consistent(golden_dir):
             r = e[k]
             assert r.shape[1] == 11 and np.array_equal(r[:, 5], r[np.arange(len(r)), 7 + r[:, 6].astype(int)]), k      # score = prob[class]
             assert (r[:, 10] > 0).all(), k                                                                              # variance = exp(.)
-    sds, sets = load_fused_fixture(golden_dir)
-    assert len(sets) >= 4, "at least four evaluation sets with both detectors' rows"
+    assert sum(1 for k in e.files if k.startswith("t_") and "r_" + k[2:] in e.files) >= 4, "at least four evaluation sets with both detectors' rows"
+    sds, sets = load_fused_fixture(golden_dir, max_sets=1)
     name, ft, fr, gts, ot, orr = sets[0]
     # the RGB detector's first frame through the oracle (the thermal one is covered by the test above)
     new_hw = resize_shortest_edge_shape(512, 640, 800, 1333)
