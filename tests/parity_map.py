@@ -286,12 +286,12 @@ def classify_fused(rows, idx, other, own_inputs_only):
     return cls
 
 
-def measure_fused(golden_dir, methods=FUSED_METHODS, flips=True):
+def measure_fused(golden_dir, methods=FUSED_METHODS, flips=True, max_sets=None):
     """Per method and evaluation set: AP table of oracle-detectors -> oracle.proben (the reference's route) and of HIP detectors ->
     pe_proben_fuse_batch (the product's route) against the same ground truth; deltas, mean, standard error; the flip classes of the
     fused rows (and, for scale, the same deltas of the two detectors alone on these sets)."""
     from proben_amd.rcnn import DetectorConfig, GeneralizedRCNN
-    sds, sets = load_fused_fixture(golden_dir)
+    sds, sets = load_fused_fixture(golden_dir, max_sets=max_sets)      # max_sets: the first few sets (in seed order) only
     models = [GeneralizedRCNN(DetectorConfig(), sd) for sd in sds]
     rec = {"models": "two R101-FPN, seeded random backbones (seeds 1 / 2), RPN + box predictor fitted on the thermal / RGB rendering of the same "
                      "scenes (tests/golden/gen_pseudo_heads.py, gen_fused_map.py; 20 % of the objects invisible to the RGB detector)",

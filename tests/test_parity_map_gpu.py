@@ -99,9 +99,12 @@ _FREC = {}
 
 def fused_record(golden_dir):
     from parity_map import measure_fused
-    if "rec" not in _FREC:
-        _FREC["rec"] = measure_fused(golden_dir, flips=False)
+    if "rec" not in _FREC:      # the first twelve of the fixture's twenty-four sets are measured LIVE here (two minutes of the suite); all of them
+        _FREC["rec"] = measure_fused(golden_dir, flips=False, max_sets=LIVE_SETS)      # by scripts/fused_map.py -> profiles/r06_fused_map.json (below)
     return _FREC["rec"]
+
+
+LIVE_SETS = 12
 
 
 # per-set bounds = |mean| + 3 sigma of the per-set deltas of profiles/r06_fused_map.json, rounded up to a tenth; the fused figures scatter
@@ -132,8 +135,19 @@ def test_fused_map_is_consistent_with_the_north_star_tolerance(golden_dir):
     method pairs, i.e. the tolerance is not rejected; whether the standard error itself is below 0.1 is reported in profiles/r06_fused_map.json
     (twenty-four sets, 6 144 frames: probEn / v-avg +0.12 / +0.13 / +0.37 with standard errors 0.05 / 0.07 / 0.22 - the product route a tenth of a
     point ABOVE the oracle route, 2.4 SE on AP -, avg / s-avg -0.01 / +0.04 / +0.09 with 0.09 / 0.11 / 0.20)."""
-    rec = fused_record(golden_dir)
-    for method, m in rec["methods"].items():
-        for n in ("AP", "AP50", "AP75"):
-            se = m["delta_standard_error"][n]
-            assert abs(m["delta_mean"][n]) <= NORTH_STAR_POINTS + 2 * se, (method, n, m["delta_mean"], m["delta_standard_error"])
+    import json
+    committed = json.load(open(os.path.join(os.path.dirname(golden_dir.rstrip("/")), "..", "profiles", "r06_fused_map.json")))
+    live = fused_record(golden_dir)
+    for rec, n_min in ((live, LIVE_SETS), (committed, 24)):
+        for method, m in rec["methods"].items():
+            assert m["n_sets"] >= n_min, (method, m["n_sets"])
+            for n in ("AP", "AP50", "AP75"):
+                se = m["delta_standard_error"][n]
+                assert abs(m["delta_mean"][n]) <= NORTH_STAR_POINTS + 2 * se, (method, n, m["delta_mean"], m["delta_standard_error"])
+    # the committed record is the measurement of the SAME sets: what the live run finds for a set is what the record holds for it (the kernels
+    # are deterministic; the record was written on the final kernels of the round)
+    for method, m in live["methods"].items():
+        for name, s in m["sets"].items():
+            c = committed["methods"][method]["sets"][name]
+            for n in ("AP", "AP50", "AP75"):
+                assert abs(s["delta"][n] - c["delta"][n]) <= 1e-6, (method, name, n, s["delta"][n], c["delta"][n])
