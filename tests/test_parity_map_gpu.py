@@ -109,8 +109,8 @@ LIVE_SETS = 12
 
 # per-set bounds = |mean| + 3 sigma of the per-set deltas of profiles/r06_fused_map.json, rounded up to a tenth; the fused figures scatter
 # 2-3 x wider than a single detector's (twenty-four sets: std 0.24 / 0.35 / 1.08 for probEn / v-avg, 0.43 / 0.53 / 0.96 for avg / s-avg against
-# 0.19 / 0.23 / 0.47 for the thermal detector alone; the bounds were fixed on the first twelve sets and the twelve added later met them): ProbEn SATURATES scores (7 % of the fused rows carry exactly 1.0f, 29 % >= 0.999), COCO's AP
-# depends on the order of tied scores, and one flipped member moves the averaged box of its whole cluster
+# 0.19 / 0.23 / 0.47 for the thermal detector alone; the bounds were fixed on the first twelve sets and the twelve added later met them): one flipped member moves the pivot, the membership or the averaged box of its whole cluster; the ORDER of tied scores
+# (7 % of the fused rows carry exactly 1.0f, 29 % >= 0.999) is not it: 0.005 point (profiles/r06_fused_tie_probe.txt)
 FUSED_PER_SET_BOUND = {"probEn/v-avg": {"AP": 1.0, "AP50": 1.5, "AP75": 3.5}, "avg/s-avg": {"AP": 1.5, "AP50": 1.8, "AP75": 3.5}}
 
 
